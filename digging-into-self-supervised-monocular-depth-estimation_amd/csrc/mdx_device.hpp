@@ -1,0 +1,278 @@
+// mdx_device.hpp -- per-pixel device math of the photometric path, gfx950.
+//
+// Every function states the reference line it reproduces and the OPERATION ORDER that makes the
+// float32 result bit-identical to the reference's CPU (ATen) execution.  The translation unit is
+// compiled with -ffp-contract=off: a fused multiply-add happens only where __builtin_fmaf is written,
+// every other mul/add is rounded separately, and `/` is the correctly rounded IEEE divide.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MDX_DEV __device__ __forceinline__
+
+namespace mdx {
+
+// ---------------------------------------------------------------------------------------------
+// A1  bilinear upsample, align_corners=False  (warp.py:18-20 via processor.py:142)
+// ---------------------------------------------------------------------------------------------
+struct UpTap { int i0, i1; float l0, l1; };
+
+MDX_DEV UpTap up_tap(float scale, int dst, int in_size)
+{
+    // ATen area_pixel_compute_source_index: scale*(dst+0.5)-0.5, clamped at 0
+    float src = scale * ((float)dst + 0.5f) - 0.5f;
+    src = src < 0.f ? 0.f : src;
+    int a = (int)src;
+    a = a > in_size - 1 ? in_size - 1 : a;
+    UpTap t;
+    t.i0 = a;
+    t.i1 = a + (a < in_size - 1 ? 1 : 0);
+    t.l1 = src - (float)a;
+    t.l0 = 1.0f - t.l1;
+    return t;
+}
+
+// premul: ATen's small-output kernel (H+W <= 128); else the generic separable kernel
+MDX_DEV float up_combine(float v00, float v01, float v10, float v11, const UpTap &ty, const UpTap &tx,
+                         bool premul)
+{
+    if (premul) {
+        float w00 = ty.l0 * tx.l0, w01 = ty.l0 * tx.l1, w10 = ty.l1 * tx.l0, w11 = ty.l1 * tx.l1;
+        float acc = w01 * v01;
+        acc = __builtin_fmaf(w00, v00, acc);
+        acc = __builtin_fmaf(w10, v10, acc);
+        return __builtin_fmaf(w11, v11, acc);
+    }
+    float top = __builtin_fmaf(tx.l0, v00, tx.l1 * v01);
+    float bot = __builtin_fmaf(tx.l0, v10, tx.l1 * v11);
+    return __builtin_fmaf(ty.l0, top, ty.l1 * bot);
+}
+
+MDX_DEV float upsample_at(const float *__restrict__ disp, int h, int w, int H, int W, int y, int x,
+                          bool premul)
+{
+    if (h == H && w == W) return disp[y * w + x];
+    UpTap ty = up_tap((float)h / (float)H, y, h);
+    UpTap tx = up_tap((float)w / (float)W, x, w);
+    return up_combine(disp[ty.i0 * w + tx.i0], disp[ty.i0 * w + tx.i1], disp[ty.i1 * w + tx.i0],
+                      disp[ty.i1 * w + tx.i1], ty, tx, premul);
+}
+
+// ---------------------------------------------------------------------------------------------
+// A2  disparity2depth (warp.py:34-39): sd = a + b*disp (mul, then add); depth = 1/sd
+// ---------------------------------------------------------------------------------------------
+MDX_DEV float scaled_disp(float disp, float a, float b)
+{
+    float t = b * disp;
+    return a + t;
+}
+
+// ---------------------------------------------------------------------------------------------
+// A4  Depth2PointCloud (warp.py:238-242): r = invK[:3,:3] @ (x,y,1) as MKL's k-ordered FMA chain
+// ---------------------------------------------------------------------------------------------
+MDX_DEV void pixel_ray(const float *__restrict__ invK, float x, float y, float r[3])
+{
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float t = invK[i * 4 + 0] * x;
+        t = __builtin_fmaf(invK[i * 4 + 1], y, t);
+        r[i] = __builtin_fmaf(invK[i * 4 + 2], 1.0f, t);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// A5  PointCloud2Pixel (warp.py:261-268)
+// ---------------------------------------------------------------------------------------------
+struct Proj { float u, v, z, gx, gy; };
+
+MDX_DEV Proj project_point(const float *__restrict__ P, float X0, float X1, float X2, float X3, int H,
+                           int W, float eps)
+{
+    float q[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float t = P[i * 4 + 0] * X0;
+        t = __builtin_fmaf(P[i * 4 + 1], X1, t);
+        t = __builtin_fmaf(P[i * 4 + 2], X2, t);
+        q[i] = __builtin_fmaf(P[i * 4 + 3], X3, t);
+    }
+    Proj p;
+    p.z = q[2] + eps;
+    p.u = q[0] / p.z;
+    p.v = q[1] / p.z;
+    float nx = p.u / (float)(W - 1);
+    float ny = p.v / (float)(H - 1);
+    p.gx = (nx - 0.5f) * 2.0f;
+    p.gy = (ny - 0.5f) * 2.0f;
+    return p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// A6  grid_sample bilinear / border / align_corners=True (warp.py:12-14)
+// ---------------------------------------------------------------------------------------------
+struct Tap {
+    int x0, y0;
+    float nw, ne, sw, se;
+    float ix, iy;
+    bool inx, iny;   // unclipped coordinate strictly inside -> gradient passes
+};
+
+MDX_DEV Tap make_tap(float gx, float gy, int H, int W)
+{
+    Tap t;
+    float ix = (gx + 1.0f) * ((float)(W - 1) / 2.0f);
+    float iy = (gy + 1.0f) * ((float)(H - 1) / 2.0f);
+    t.inx = (ix > 0.f) && (ix < (float)(W - 1));
+    t.iny = (iy > 0.f) && (iy < (float)(H - 1));
+    ix = fminf((float)(W - 1), fmaxf(ix, 0.f));
+    iy = fminf((float)(H - 1), fmaxf(iy, 0.f));
+    float xw = floorf(ix), yn = floorf(iy);
+    float w = ix - xw, e = 1.0f - w, n = iy - yn, s = 1.0f - n;
+    t.nw = s * e; t.ne = s * w; t.sw = n * e; t.se = n * w;
+    t.x0 = (int)xw; t.y0 = (int)yn;
+    t.ix = ix; t.iy = iy;
+    return t;
+}
+
+struct Corners { float nw, ne, sw, se; };
+
+// out-of-range corners read as 0 (ATen's masked gather); x0,y0 are always in range after clipping
+MDX_DEV Corners load_corners(const float *__restrict__ img, int H, int W, const Tap &t)
+{
+    bool xe = t.x0 + 1 < W, ys = t.y0 + 1 < H;
+    const float *p = img + (size_t)t.y0 * W + t.x0;
+    Corners c;
+    c.nw = p[0];
+    c.ne = xe ? p[1] : 0.f;
+    c.sw = ys ? p[W] : 0.f;
+    c.se = (xe && ys) ? p[W + 1] : 0.f;
+    return c;
+}
+
+MDX_DEV float sample(const Corners &c, const Tap &t)
+{
+    float acc = c.nw * t.nw;
+    acc = __builtin_fmaf(c.ne, t.ne, acc);
+    acc = __builtin_fmaf(c.sw, t.sw, acc);
+    return __builtin_fmaf(c.se, t.se, acc);
+}
+
+// ---------------------------------------------------------------------------------------------
+// A7/A8  SSIM + L1 (model_loss.py:28-41, 97-103)
+// ---------------------------------------------------------------------------------------------
+#define MDX_C1 0.0001f   // 0.01 ** 2
+#define MDX_C2 0.0009f   // 0.03 ** 2
+
+MDX_DEV int reflect(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+// AvgPool2d(3,1): row-major sequential sum of the nine taps, then a true divide by 9
+MDX_DEV float pool9(const float v[9])
+{
+    float s = v[0];
+#pragma unroll
+    for (int k = 1; k < 9; ++k) s = s + v[k];
+    return s / 9.0f;
+}
+
+struct TargetStats { float mu, e2, mu2; };   // mu_y, pool(y*y), mu_y*mu_y
+
+MDX_DEV TargetStats target_stats(const float y[9])
+{
+    float yy[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) yy[k] = y[k] * y[k];
+    TargetStats t;
+    t.mu = pool9(y);
+    t.e2 = pool9(yy);
+    t.mu2 = t.mu * t.mu;
+    return t;
+}
+
+struct SsimTerms { float mu_x, ex2, exy; };
+
+MDX_DEV SsimTerms pred_stats(const float x[9], const float y[9])
+{
+    float xx[9], xy[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { xx[k] = x[k] * x[k]; xy[k] = x[k] * y[k]; }
+    SsimTerms s;
+    s.mu_x = pool9(x);
+    s.ex2 = pool9(xx);
+    s.exy = pool9(xy);
+    return s;
+}
+
+// returns the un-clamped (1 - n/d)/2; the SSIM map value is clamp(raw, 0, 1)
+MDX_DEV float ssim_raw(const SsimTerms &s, const TargetStats &t)
+{
+    float mxx = s.mu_x * s.mu_x;
+    float mxy = s.mu_x * t.mu;
+    float sig_x = s.ex2 - mxx;
+    float sig_y = t.e2 - t.mu2;
+    float sig_xy = s.exy - mxy;
+    float a = 2.0f * s.mu_x;
+    a = a * t.mu;
+    float A1 = a + MDX_C1;
+    float A2 = 2.0f * sig_xy;
+    A2 = A2 + MDX_C2;
+    float n = A1 * A2;
+    float B1 = (mxx + t.mu2) + MDX_C1;
+    float B2 = (sig_x + sig_y) + MDX_C2;
+    float d = B1 * B2;
+    return (1.0f - n / d) / 2.0f;
+}
+
+MDX_DEV float clamp01(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
+
+// ReprojectionLoss from per-channel SSIM and |y-x|: ((c0+c1)+c2)/3 means; 0.85f*ssim + 0.15f*l1
+MDX_DEV float reprojection_combine(const float ssim[3], const float ad[3])
+{
+    float l1 = (ad[0] + ad[1]) + ad[2];
+    float ss = (ssim[0] + ssim[1]) + ssim[2];
+    l1 = l1 / 3.0f;
+    ss = ss / 3.0f;
+    float a = 0.85f * ss, b = 0.15f * l1;
+    return a + b;
+}
+
+// closed-form d(clamped SSIM)/d(window sums) for one channel
+//   grad wrt padded x at a tap with values (xq, yq): (alpha + 2*xq*beta + yq*gamma) / 9
+struct SsimGrad { float alpha, beta, gamma; };
+
+MDX_DEV SsimGrad ssim_grad(const SsimTerms &s, const TargetStats &t, float g)
+{
+    float mx = s.mu_x, my = t.mu;
+    float sig_x = s.ex2 - mx * mx, sig_y = t.e2 - t.mu2, sig_xy = s.exy - mx * my;
+    float A1 = 2.0f * mx * my + MDX_C1, A2 = 2.0f * sig_xy + MDX_C2;
+    float B1 = mx * mx + t.mu2 + MDX_C1, B2 = sig_x + sig_y + MDX_C2;
+    float n = A1 * A2, d = B1 * B2;
+    float raw = (1.0f - n / d) * 0.5f;
+    SsimGrad r;
+    if (!(raw >= 0.f && raw <= 1.f)) { r.alpha = r.beta = r.gamma = 0.f; return r; }
+    float inv_d = 1.0f / d;
+    float Ln = -0.5f * inv_d, Ld = 0.5f * n * inv_d * inv_d;
+    float dA1 = Ln * A2, dA2 = Ln * A1, dB1 = Ld * B2, dB2 = Ld * B1;
+    r.alpha = g * 2.0f * (my * (dA1 - dA2) + mx * (dB1 - dB2));
+    r.beta = g * dB2;
+    r.gamma = g * 2.0f * dA2;
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// reductions: wave64 shuffle tree, then LDS across the waves of the block
+// ---------------------------------------------------------------------------------------------
+MDX_DEV double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+MDX_DEV float wave_sum(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+}  // namespace mdx

@@ -1,0 +1,100 @@
+"""ctypes binding of libmdx_hip.so (include/mdx.h).  No torch types cross this boundary: tensors are
+handed over as raw device pointers + sizes, the current HIP stream as a void*.
+
+There is NO fallback: if the library is missing or a tensor is not a contiguous float32 CUDA/HIP
+tensor, the call raises.
+"""
+import ctypes as C
+import os
+
+import torch
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "libmdx_hip.so")
+MAX_SRC = 4
+FLAG_AUTOMASK = 1
+_lib = None
+
+
+class MdxError(RuntimeError):
+    pass
+
+
+class Desc(C.Structure):
+    _fields_ = [("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("h", C.c_int32), ("w", C.c_int32),
+                ("S", C.c_int32), ("flags", C.c_uint32), ("disp_a", C.c_float), ("disp_b", C.c_float)]
+
+
+class Sources(C.Structure):
+    _fields_ = [("img", C.c_void_p * MAX_SRC)]
+
+
+# every symbol include/mdx.h declares: name -> restype (None = int status)
+SYMBOLS = {
+    "mdx_version": C.c_int, "mdx_status_string": C.c_char_p, "mdx_desc_init": C.c_int,
+    "mdx_compose_projection": C.c_int, "mdx_identity_loss": C.c_int,
+    "mdx_photometric_workspace_bytes": C.c_size_t, "mdx_photometric_fwd": C.c_int,
+    "mdx_photometric_bwd": C.c_int, "mdx_smooth_workspace_bytes": C.c_size_t, "mdx_smooth_loss": C.c_int,
+    "mdx_interpolate_bilinear_fwd": C.c_int, "mdx_interpolate_bilinear_bwd": C.c_int,
+    "mdx_disparity2depth_fwd": C.c_int, "mdx_disparity2depth_bwd": C.c_int,
+    "mdx_backproject_fwd": C.c_int, "mdx_backproject_bwd": C.c_int,
+    "mdx_project_workspace_bytes": C.c_size_t, "mdx_project_fwd": C.c_int, "mdx_project_bwd": C.c_int,
+    "mdx_grid_sample_border_fwd": C.c_int, "mdx_grid_sample_border_bwd": C.c_int,
+    "mdx_reprojection_loss_fwd": C.c_int, "mdx_reprojection_loss_bwd": C.c_int, "mdx_ssim_fwd": C.c_int,
+    "mdx_min_automask_fwd": C.c_int,
+}
+
+
+def lib():
+    """Loads libmdx_hip.so; raises MdxError loudly if it is absent or incomplete."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MdxError("libmdx_hip.so not found at %s -- build it with "
+                           "`python __graft_entry__.py build` (hipcc --offload-arch=gfx950); "
+                           "there is no CPU/eager fallback" % LIB_PATH)
+        handle = C.CDLL(LIB_PATH)
+        for name, res in SYMBOLS.items():
+            try:
+                getattr(handle, name).restype = res
+            except AttributeError:
+                raise MdxError("libmdx_hip.so does not export %s (stale build?)" % name)
+        _lib = handle
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        raise MdxError("%s failed: %s (%d)" % (what, lib().mdx_status_string(status).decode(), status))
+
+
+def ptr(t, dtype=torch.float32, optional=False):
+    """Raw device pointer of a contiguous CUDA/HIP tensor."""
+    if t is None:
+        if optional:
+            return None
+        raise MdxError("required tensor is None")
+    if not t.is_cuda:
+        raise MdxError("mdx kernels run on the GPU only: got a %s tensor (no CPU fallback)" % t.device)
+    if t.dtype != dtype or not t.is_contiguous():
+        raise MdxError("expected contiguous %s, got %s contiguous=%s" % (dtype, t.dtype, t.is_contiguous()))
+    return C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def make_desc(B, H, W, h, w, S, automask, min_depth, max_depth):
+    d = Desc()
+    check(lib().mdx_desc_init(C.byref(d), B, H, W, h, w, S, int(bool(automask)), C.c_double(min_depth),
+                              C.c_double(max_depth)), "mdx_desc_init")
+    return d
+
+
+def make_sources(tensors):
+    s = Sources()
+    if not 1 <= len(tensors) <= MAX_SRC:
+        raise MdxError("1..%d source frames supported, got %d" % (MAX_SRC, len(tensors)))
+    for i, t in enumerate(tensors):
+        s.img[i] = ptr(t).value
+    return s

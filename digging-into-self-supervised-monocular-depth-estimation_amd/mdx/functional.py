@@ -1,0 +1,366 @@
+"""Autograd functions over the libmdx_hip.so C-ABI.
+
+Fused path (what the training step runs):
+    compose_projection(K, T)                   -> P = (K@T)[:, :3]      (warp.py:260)
+    identity_loss(target, sources)             -> [B,S,H,W]             (processor.py:187-191)
+    photometric_scale(disp, P, target, ...)    -> sum(to_optimise), idx (processor.py:141-162,172-204)
+    smooth_loss(disp, color)                   -> scalar                (model_loss.py:107-116)
+Fine-grained ops mirror model_layer/warp.py and model_loss/model_loss.py one to one.
+All tensors must be CUDA/HIP float32; there is no CPU path.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import check, lib, ptr, stream
+
+
+def _f32c(t):
+    return t.contiguous().float() if (t.dtype != torch.float32 or not t.is_contiguous()) else t
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 8) // 8 + 1, dtype=torch.float64, device=device)
+
+
+# ------------------------------------------------------------------------------------------------
+# fused path
+# ------------------------------------------------------------------------------------------------
+class _ComposeProjection(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, K, T):
+        K, T = _f32c(K), _f32c(T)
+        B = K.shape[0]
+        P = torch.empty(B, 3, 4, device=K.device, dtype=torch.float32)
+        check(lib().mdx_compose_projection(ptr(K), ptr(T), B, ptr(P), stream()), "mdx_compose_projection")
+        ctx.save_for_backward(K, T)
+        return P
+
+    @staticmethod
+    def backward(ctx, gP):
+        K, T = ctx.saved_tensors
+        gK = gT = None
+        if ctx.needs_input_grad[1]:
+            gT = torch.matmul(K[:, :3, :].transpose(1, 2), gP)
+        if ctx.needs_input_grad[0]:
+            gK = torch.zeros_like(K)
+            gK[:, :3, :] = torch.matmul(gP, T.transpose(1, 2))
+        return gK, gT
+
+
+def compose_projection(K, T):
+    """(K @ T)[:, :3, :] with ATen-CPU's rounding order.  K, T: [B,4,4] -> [B,3,4]."""
+    return _ComposeProjection.apply(K, T)
+
+
+def identity_loss(target, sources, desc=None):
+    """ReprojectionLoss(color_f, target) for every source frame -> [B,S,H,W] (no grad: inputs only)."""
+    target = _f32c(target)
+    sources = [_f32c(s) for s in sources]
+    B, _, H, W = target.shape
+    S = len(sources)
+    d = desc or _lib.make_desc(B, H, W, H, W, S, True, 0.1, 100.0)
+    src = _lib.make_sources(sources)
+    out = torch.empty(B, S, H, W, device=target.device, dtype=torch.float32)
+    check(lib().mdx_identity_loss(C.byref(d), ptr(target), C.byref(src), ptr(out), stream()), "mdx_identity_loss")
+    return out
+
+
+class _PhotometricScale(torch.autograd.Function):
+    """One scale: returns (sum over pixels of to_optimise [1], idx uint8 [B,H,W], extras...)."""
+
+    @staticmethod
+    def forward(ctx, disp, P, target, invK, ident, noise, cfg, *sources):
+        disp, P, target, invK = _f32c(disp), _f32c(P), _f32c(target), _f32c(invK)
+        sources = [_f32c(s) for s in sources]
+        B, _, h, w = disp.shape
+        _, _, H, W = target.shape
+        S = len(sources)
+        automask = cfg["automask"]
+        d = _lib.make_desc(B, H, W, h, w, S, automask, cfg["min_depth"], cfg["max_depth"])
+        src = _lib.make_sources(sources)
+        dev = disp.device
+        if automask:
+            ident, noise = _f32c(ident), _f32c(noise)
+        idx = torch.empty(B, H, W, device=dev, dtype=torch.uint8)
+        loss_sum = torch.empty(1, device=dev, dtype=torch.float32)
+        to_opt = torch.empty(B, H, W, device=dev, dtype=torch.float32) if cfg.get("need_to_opt") else None
+        depth = torch.empty(B, 1, H, W, device=dev, dtype=torch.float32) if cfg.get("need_depth") else None
+        warp = torch.empty(S, B, 3, H, W, device=dev, dtype=torch.float32) if cfg.get("need_warp") else None
+        reproj = torch.empty(B, S, H, W, device=dev, dtype=torch.float32) if cfg.get("need_reproj") else None
+        nws = lib().mdx_photometric_workspace_bytes(C.byref(d))
+        ws = _ws(nws, dev)
+        check(lib().mdx_photometric_fwd(
+            C.byref(d), ptr(disp), ptr(target), C.byref(src), ptr(invK), ptr(P),
+            ptr(ident, optional=True) if automask else None, ptr(noise, optional=True) if automask else None,
+            ptr(idx, torch.uint8), ptr(loss_sum), ptr(to_opt, optional=True), ptr(depth, optional=True),
+            ptr(warp, optional=True), ptr(reproj, optional=True), ptr(ws, torch.float64), C.c_size_t(nws),
+            stream()), "mdx_photometric_fwd")
+        ctx.save_for_backward(disp, P, target, invK, idx, *sources)
+        ctx.cfg = dict(cfg)
+        ctx.mark_non_differentiable(*[t for t in (idx, to_opt, depth, warp, reproj) if t is not None])
+        return (loss_sum, idx, to_opt, depth, warp, reproj)
+
+    @staticmethod
+    def backward(ctx, g_sum, *_unused):
+        disp, P, target, invK, idx, *sources = ctx.saved_tensors
+        cfg = ctx.cfg
+        B, _, h, w = disp.shape
+        _, _, H, W = target.shape
+        S = len(sources)
+        d = _lib.make_desc(B, H, W, h, w, S, cfg["automask"], cfg["min_depth"], cfg["max_depth"])
+        src = _lib.make_sources(sources)
+        dev = disp.device
+        gdisp = torch.empty_like(disp)
+        gP = torch.empty(S, B, 3, 4, device=dev, dtype=torch.float32)
+        g_dev = _f32c(g_sum.reshape(1))
+        nws = lib().mdx_photometric_workspace_bytes(C.byref(d))
+        ws = _ws(nws, dev)
+        check(lib().mdx_photometric_bwd(
+            C.byref(d), ptr(disp), ptr(target), C.byref(src), ptr(invK), ptr(P), ptr(idx, torch.uint8),
+            C.c_float(1.0), ptr(g_dev), ptr(gdisp), ptr(gP), ptr(ws, torch.float64), C.c_size_t(nws),
+            stream()), "mdx_photometric_bwd")
+        return (gdisp, gP, None, None, None, None, None) + (None,) * S
+
+
+def photometric_scale(disp, P, target, sources, invK, ident=None, noise=None, automask=True,
+                      min_depth=0.1, max_depth=100.0, need_to_opt=False, need_depth=False,
+                      need_warp=False, need_reproj=False):
+    """Fused warp + SSIM/L1 + min for one scale.
+
+    disp [B,1,h,w] (grad), P [S,B,3,4] (grad), target [B,3,H,W], sources: list of S [B,3,H,W],
+    invK [B,4,4], ident/noise [B,S,H,W] (automask).  Returns dict with
+    'sum' ([1], differentiable; divide by B*H*W for to_optimise.mean()), 'idx' (uint8 [B,H,W]) and the
+    optional 'to_opt', 'depth', 'warp' ([S,B,3,H,W]), 'reproj' ([B,S,H,W]).
+    """
+    cfg = dict(automask=bool(automask), min_depth=float(min_depth), max_depth=float(max_depth),
+               need_to_opt=need_to_opt, need_depth=need_depth, need_warp=need_warp, need_reproj=need_reproj)
+    out = _PhotometricScale.apply(disp, P, target, invK, ident, noise, cfg, *sources)
+    return dict(zip(("sum", "idx", "to_opt", "depth", "warp", "reproj"), out))
+
+
+class _SmoothLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, disp, color, normalize=True):
+        disp, color = _f32c(disp), _f32c(color)
+        B, _, h, w = disp.shape
+        dev = disp.device
+        loss = torch.empty(1, device=dev, dtype=torch.float32)
+        need = ctx.needs_input_grad[0]
+        g = torch.empty_like(disp) if need else None
+        nws = lib().mdx_smooth_workspace_bytes(B, h, w)
+        ws = _ws(nws, dev)
+        check(lib().mdx_smooth_loss(B, h, w, ptr(disp), ptr(color), int(normalize), ptr(loss), ptr(g, optional=True),
+                                    ptr(ws, torch.float64), C.c_size_t(nws), stream()), "mdx_smooth_loss")
+        if need:
+            ctx.save_for_backward(g)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        (g,) = ctx.saved_tensors
+        return g * gout, None, None
+
+
+def smooth_loss(disp, color, normalize=True):
+    """SmoothLoss()(disp, color) -> scalar (model_loss.py:107-116); normalize=False is the bare
+    EdgeAwareSmooth (model_loss.py:77-88)."""
+    return _SmoothLoss.apply(disp, color, normalize)
+
+
+# ------------------------------------------------------------------------------------------------
+# fine-grained ops (reference API granularity)
+# ------------------------------------------------------------------------------------------------
+class _Interpolate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, H, W):
+        x = _f32c(x)
+        B, Cc, h, w = x.shape
+        out = torch.empty(B, Cc, H, W, device=x.device, dtype=torch.float32)
+        check(lib().mdx_interpolate_bilinear_fwd(ptr(x), B * Cc, h, w, ptr(out), H, W, stream()),
+              "mdx_interpolate_bilinear_fwd")
+        ctx.shape = (B, Cc, h, w, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, Cc, h, w, H, W = ctx.shape
+        g = _f32c(g)
+        gin = torch.empty(B, Cc, h, w, device=g.device, dtype=torch.float32)
+        check(lib().mdx_interpolate_bilinear_bwd(ptr(g), B * Cc, H, W, ptr(gin), h, w, stream()),
+              "mdx_interpolate_bilinear_bwd")
+        return gin, None, None
+
+
+def interpolate_bilinear(x, H, W):
+    return _Interpolate.apply(x, int(H), int(W))
+
+
+class _Disp2Depth(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, disp, min_depth, max_depth):
+        disp = _f32c(disp)
+        sd, depth = torch.empty_like(disp), torch.empty_like(disp)
+        check(lib().mdx_disparity2depth_fwd(ptr(disp), C.c_size_t(disp.numel()), C.c_double(min_depth),
+                                            C.c_double(max_depth), ptr(sd), ptr(depth), stream()),
+              "mdx_disparity2depth_fwd")
+        ctx.save_for_backward(disp)
+        ctx.mm = (min_depth, max_depth)
+        return sd, depth
+
+    @staticmethod
+    def backward(ctx, gsd, gdepth):
+        (disp,) = ctx.saved_tensors
+        gsd = _f32c(gsd) if gsd is not None else None
+        gdepth = _f32c(gdepth) if gdepth is not None else None
+        if gsd is None and gdepth is None:
+            return None, None, None
+        g = torch.empty_like(disp)
+        check(lib().mdx_disparity2depth_bwd(ptr(disp), ptr(gsd, optional=True), ptr(gdepth, optional=True),
+                                            C.c_size_t(disp.numel()), C.c_double(ctx.mm[0]),
+                                            C.c_double(ctx.mm[1]), ptr(g), stream()), "mdx_disparity2depth_bwd")
+        return g, None, None
+
+
+def disparity2depth(disp, min_depth, max_depth):
+    return _Disp2Depth.apply(disp, float(min_depth), float(max_depth))
+
+
+class _Backproject(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, depth, invK):
+        depth, invK = _f32c(depth), _f32c(invK)
+        B, _, H, W = depth.shape
+        cam = torch.empty(B, 4, H * W, device=depth.device, dtype=torch.float32)
+        check(lib().mdx_backproject_fwd(ptr(depth), ptr(invK), B, H, W, ptr(cam), stream()), "mdx_backproject_fwd")
+        ctx.save_for_backward(invK)
+        ctx.shape = (B, H, W)
+        return cam
+
+    @staticmethod
+    def backward(ctx, gcam):
+        (invK,) = ctx.saved_tensors
+        B, H, W = ctx.shape
+        gcam = _f32c(gcam)
+        gdepth = torch.empty(B, 1, H, W, device=gcam.device, dtype=torch.float32)
+        check(lib().mdx_backproject_bwd(ptr(gcam), ptr(invK), B, H, W, ptr(gdepth), stream()), "mdx_backproject_bwd")
+        return gdepth, None
+
+
+def backproject(depth, invK):
+    return _Backproject.apply(depth, invK)
+
+
+class _Project(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cam, P, H, W, eps):
+        cam, P = _f32c(cam), _f32c(P)
+        B = cam.shape[0]
+        grid = torch.empty(B, H, W, 2, device=cam.device, dtype=torch.float32)
+        check(lib().mdx_project_fwd(ptr(cam), ptr(P), B, H, W, C.c_float(eps), ptr(grid), stream()), "mdx_project_fwd")
+        ctx.save_for_backward(cam, P)
+        ctx.dims = (B, H, W, eps)
+        return grid
+
+    @staticmethod
+    def backward(ctx, ggrid):
+        cam, P = ctx.saved_tensors
+        B, H, W, eps = ctx.dims
+        ggrid = _f32c(ggrid)
+        gcam = torch.empty_like(cam)
+        gP = torch.empty_like(P)
+        nws = lib().mdx_project_workspace_bytes(B, H, W)
+        ws = _ws(nws, cam.device)
+        check(lib().mdx_project_bwd(ptr(cam), ptr(P), ptr(ggrid), B, H, W, C.c_float(eps), ptr(gcam), ptr(gP),
+                                    ptr(ws, torch.float64), C.c_size_t(nws), stream()), "mdx_project_bwd")
+        return gcam, gP, None, None, None
+
+
+def project(cam, P, H, W, eps=1e-7):
+    return _Project.apply(cam, P, int(H), int(W), float(eps))
+
+
+class _GridSampleBorder(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, grid):
+        img, grid = _f32c(img), _f32c(grid)
+        B, Cc, Hi, Wi = img.shape
+        _, Ho, Wo, _ = grid.shape
+        out = torch.empty(B, Cc, Ho, Wo, device=img.device, dtype=torch.float32)
+        check(lib().mdx_grid_sample_border_fwd(ptr(img), ptr(grid), B, Cc, Hi, Wi, Ho, Wo, ptr(out), stream()),
+              "mdx_grid_sample_border_fwd")
+        ctx.save_for_backward(img, grid)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        img, grid = ctx.saved_tensors
+        B, Cc, Hi, Wi = img.shape
+        _, Ho, Wo, _ = grid.shape
+        gout = _f32c(gout)
+        ggrid = torch.empty_like(grid)
+        gimg = torch.empty_like(img) if ctx.needs_input_grad[0] else None
+        check(lib().mdx_grid_sample_border_bwd(ptr(img), ptr(grid), ptr(gout), B, Cc, Hi, Wi, Ho, Wo, ptr(ggrid),
+                                               ptr(gimg, optional=True), stream()), "mdx_grid_sample_border_bwd")
+        return gimg, ggrid
+
+
+def grid_sample_border(img, grid):
+    return _GridSampleBorder.apply(img, grid)
+
+
+class _ReprojectionLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target):
+        pred, target = _f32c(pred), _f32c(target)
+        B, _, H, W = pred.shape
+        out = torch.empty(B, 1, H, W, device=pred.device, dtype=torch.float32)
+        check(lib().mdx_reprojection_loss_fwd(ptr(pred), ptr(target), B, H, W, ptr(out), stream()),
+              "mdx_reprojection_loss_fwd")
+        ctx.save_for_backward(pred, target)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        pred, target = ctx.saved_tensors
+        B, _, H, W = pred.shape
+        gout = _f32c(gout)
+        gp = torch.empty_like(pred) if ctx.needs_input_grad[0] else None
+        gt = torch.empty_like(pred) if ctx.needs_input_grad[1] else None
+        if gp is None and gt is None:
+            return None, None
+        check(lib().mdx_reprojection_loss_bwd(ptr(pred), ptr(target), ptr(gout), B, H, W, ptr(gp, optional=True),
+                                              ptr(gt, optional=True), stream()), "mdx_reprojection_loss_bwd")
+        return gp, gt
+
+
+def reprojection_loss(pred, target):
+    return _ReprojectionLoss.apply(pred, target)
+
+
+def ssim(x, y):
+    """SSIM map (no autograd: use reprojection_loss for training)."""
+    x, y = _f32c(x), _f32c(y)
+    B, Cc, H, W = x.shape
+    out = torch.empty_like(x)
+    check(lib().mdx_ssim_fwd(ptr(x), ptr(y), B * Cc, H, W, ptr(out), stream()), "mdx_ssim_fwd")
+    return out
+
+
+def min_automask(ident, noise, reproj, automask=True, need_combined=False):
+    """identity+noise / concat / torch.min(dim=1) -> (to_opt [B,H,W], idx uint8, combined or None)."""
+    reproj = _f32c(reproj)
+    B, S, H, W = reproj.shape
+    dev = reproj.device
+    if automask:
+        ident, noise = _f32c(ident), _f32c(noise)
+    Cc = 2 * S if automask else S
+    comb = torch.empty(B, Cc, H, W, device=dev, dtype=torch.float32) if need_combined else None
+    to_opt = torch.empty(B, H, W, device=dev, dtype=torch.float32)
+    idx = torch.empty(B, H, W, device=dev, dtype=torch.uint8)
+    check(lib().mdx_min_automask_fwd(ptr(ident, optional=True) if automask else None,
+                                     ptr(noise, optional=True) if automask else None, ptr(reproj), B, S, H, W,
+                                     int(automask), ptr(comb, optional=True), ptr(to_opt), ptr(idx, torch.uint8),
+                                     stream()), "mdx_min_automask_fwd")
+    return to_opt, idx, comb

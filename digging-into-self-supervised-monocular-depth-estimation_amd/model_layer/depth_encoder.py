@@ -1,0 +1,146 @@
+"""ResNet encoder (reference: model_layer/depth_encoder.py:14-101), restated without torchvision.
+
+State-dict compatible with the reference / torchvision (`encoder.conv1.weight`,
+`encoder.layer1.0.conv1.weight`, ..., `encoder.fc.weight`).  The convolutions run on PyTorch-ROCm
+(MIOpen / hipBLASLt -> MFMA); no hand kernel here by design.
+"""
+import os
+import warnings
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+
+    def forward(self, x):
+        identity = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        return self.relu(out + identity)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        identity = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        return self.relu(out + identity)
+
+
+_CFG = {18: (BasicBlock, [2, 2, 2, 2]), 34: (BasicBlock, [3, 4, 6, 3]), 50: (Bottleneck, [3, 4, 6, 3]),
+        101: (Bottleneck, [3, 4, 23, 3]), 152: (Bottleneck, [3, 8, 36, 3])}
+
+
+class ResNet(nn.Module):
+    """torchvision.models.ResNet layout (conv1/bn1/relu/maxpool/layer1-4/avgpool/fc)."""
+
+    def __init__(self, block, layers, num_classes=1000, num_input_images=1):
+        super().__init__()
+        self.inplanes = 64
+        self.conv1 = nn.Conv2d(num_input_images * 3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.layer1 = self._make_layer(block, 64, layers[0])
+        self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
+        self.layer3 = self._make_layer(block, 256, layers[2], stride=2)
+        self.layer4 = self._make_layer(block, 512, layers[3], stride=2)
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        self.fc = nn.Linear(512 * block.expansion, num_classes)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def _make_layer(self, block, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(
+                nn.Conv2d(self.inplanes, planes * block.expansion, 1, stride, bias=False),
+                nn.BatchNorm2d(planes * block.expansion))
+        layers = [block(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * block.expansion
+        layers += [block(self.inplanes, planes) for _ in range(1, blocks)]
+        return nn.Sequential(*layers)
+
+
+def _load_pretrained(model, num_layers, num_input_images):
+    """ImageNet init (reference: depth_encoder.py:57-60,86).  There is no network here: weights are
+    read from $MDX_RESNET_WEIGHTS/resnet{N}.pth when present, otherwise the random init stays."""
+    path = os.path.join(os.environ.get("MDX_RESNET_WEIGHTS", ""), "resnet%d.pth" % num_layers)
+    if not os.path.isfile(path):
+        warnings.warn("pretrained=True but %s not found (offline): using random init" % (path or "weights"))
+        return
+    loaded = torch.load(path, map_location="cpu")
+    if num_input_images > 1:
+        loaded["conv1.weight"] = torch.cat([loaded["conv1.weight"]] * num_input_images, 1) / num_input_images
+    model.load_state_dict(loaded)
+
+
+def resnet_multiimage_input(num_layers, pretrained=True, num_input_images=1):
+    """reference: model_layer/depth_encoder.py:44-61."""
+    assert num_layers in [18, 50], "Can only run with 18 or 50 layer resnet"
+    block, layers = _CFG[num_layers]
+    model = ResNet(block, layers, num_input_images=num_input_images)
+    if pretrained:
+        _load_pretrained(model, num_layers, num_input_images)
+    return model
+
+
+class ResnetEncoder(nn.Module):
+    """reference: model_layer/depth_encoder.py:65-101.  Returns the five feature maps."""
+
+    def __init__(self, num_layers, pretrained, num_input_images=1):
+        super().__init__()
+        self.num_ch_enc = np.array([64, 64, 128, 256, 512])
+        if num_layers not in _CFG:
+            raise ValueError("{} is not a valid number of resnet layers".format(num_layers))
+        if num_input_images > 1:
+            self.encoder = resnet_multiimage_input(num_layers, pretrained, num_input_images)
+        else:
+            block, layers = _CFG[num_layers]
+            self.encoder = ResNet(block, layers)
+            if pretrained:
+                _load_pretrained(self.encoder, num_layers, 1)
+        if num_layers > 34:
+            self.num_ch_enc[1:] *= 4
+
+    def forward(self, input_image):
+        self.features = []
+        x = (input_image - 0.45) / 0.225
+        x = self.encoder.conv1(x)
+        x = self.encoder.bn1(x)
+        self.features.append(self.encoder.relu(x))
+        self.features.append(self.encoder.layer1(self.encoder.maxpool(self.features[-1])))
+        self.features.append(self.encoder.layer2(self.features[-1]))
+        self.features.append(self.encoder.layer3(self.features[-1]))
+        self.features.append(self.encoder.layer4(self.features[-1]))
+        return self.features

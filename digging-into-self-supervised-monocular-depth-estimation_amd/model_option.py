@@ -1,0 +1,42 @@
+"""Command-line options (reference: model_option.py:5-89): same flag names and defaults; list-typed flags
+are parsed properly, and the multi-GPU / precision flags the reference lacks are added."""
+import argparse
+
+
+def _ids(text):
+    return [t if t == "s" else int(t) for t in str(text).replace(",", " ").split()]
+
+
+def options(argv=None):
+    p = argparse.ArgumentParser(description="MI355X self-supervised depth training")
+    p.add_argument("--datapath", type=str, default="./dataset/kitti")
+    p.add_argument("--splits", type=str, default="./splits")
+    p.add_argument("--dataset", type=str, default="synthetic", choices=["kitti_mono", "kitti_stereo", "synthetic"])
+    p.add_argument("--datatype", type=str, default="kitti_eigen_zhou")
+    p.add_argument("--epoch", type=int, default=24)
+    p.add_argument("--batch", type=int, default=12)
+    p.add_argument("--prepetch", type=int, default=2)
+    p.add_argument("--num_workers", type=int, default=4)
+    p.add_argument("--learning_rate", type=float, default=1e-4)
+    p.add_argument("--scheduler_step", type=int, default=15)
+    p.add_argument("--disp_smoothness", type=float, default=1e-3)
+    p.add_argument("--save", type=str, default="mono")
+    p.add_argument("--height", type=int, default=192)
+    p.add_argument("--width", type=int, default=640)
+    p.add_argument("--scales", type=_ids, default=[0, 1, 2, 3])
+    p.add_argument("--min_depth", type=float, default=0.1)
+    p.add_argument("--max_depth", type=float, default=100.0)
+    p.add_argument("--frame_ids", type=_ids, default=[0, -1, 1])
+    p.add_argument("--pose_frames", type=str, default="pair", choices=["pair", "all"])
+    p.add_argument("--num_layers", type=int, default=18, choices=[18, 34, 50, 101, 152])
+    p.add_argument("--weight_init", type=lambda s: str(s).lower() in ("1", "true", "yes"), default=True)
+    p.add_argument("--pose_type", type=str, default="separate", choices=["posecnn", "shared", "separate"])
+    p.add_argument("--use_automasking", type=lambda s: str(s).lower() in ("1", "true", "yes"), default=True)
+    # additions
+    p.add_argument("--fused", type=lambda s: str(s).lower() in ("1", "true", "yes"), default=True)
+    p.add_argument("--noise", type=str, default="device", choices=["device", "cpu"])
+    p.add_argument("--amp", type=str, default="none", choices=["none", "bf16"])
+    p.add_argument("--channels_last", action="store_true")
+    p.add_argument("--synthetic_length", type=int, default=768)
+    p.add_argument("--max_steps", type=int, default=0, help="stop an epoch early (0 = full epoch)")
+    return p.parse_args(argv)

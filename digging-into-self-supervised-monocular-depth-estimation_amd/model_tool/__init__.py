@@ -1,0 +1,4 @@
+"""Drop-in for the reference's model_tool package (export list: model_tool/__init__.py:1-3)."""
+from .loader import setting
+from .logger import control
+from .processor import compute

@@ -1,0 +1,57 @@
+"""`control`: metrics, printing and checkpoints (reference: model_tool/logger.py:25-72).
+
+Same metric names and file naming (`./model_save/<save>/<key><epoch>.pt`, loss/<metric>.npy).  Unlike the
+reference, per-batch values stay on the device and are synchronised once per epoch (the reference issues
+nine device->host copies per step: model_train.py:69, logger.py:31-35)."""
+import os
+
+import numpy as np
+import torch
+
+from model_loss import compute_depth_metric
+
+
+class control(object):
+    def __init__(self, opt, device):
+        self.opt = opt
+        self.device = device
+        self.metric_name = ["loss", "abs_rel", "sq_rel", "rmse", "rmse_log", "a1", "a2", "a3"]
+
+    def metric(self, inputs, outputs, metric_dict):
+        metric_dict["loss"].append(outputs["loss"].detach())
+        if ("depth", 0) in inputs and ("depth", 0, 0) in outputs:
+            depth_errors = compute_depth_metric(inputs, outputs, "torch")
+            for index, metric in enumerate(self.metric_name[1:]):
+                metric_dict[metric].append(depth_errors[index].detach())
+        return metric_dict
+
+    @staticmethod
+    def _mean(values):
+        if not len(values):
+            return float("nan")
+        if torch.is_tensor(values[0]):
+            return float(torch.stack([v.float().reshape(()) for v in values]).mean().cpu())
+        return float(np.mean(values))
+
+    def print(self, epoch, train_log, valid_log):
+        print("EPOCH   {0}".format(epoch + 1))
+        for name, log in (("Train Log", train_log), ("Valid Log", valid_log)):
+            print(name, end=" ")
+            for key in self.metric_name:
+                print("  {} {:0.3f}".format(key, self._mean(log[key])), end=" ")
+            print(" ")
+
+    def save(self, epoch, train_log, valid_log, setting):
+        if int(os.environ.get("RANK", "0")) != 0:
+            return
+        save_directory = os.path.join("./model_save", self.opt.save)
+        loss_directory = os.path.join(save_directory, "loss")
+        os.makedirs(loss_directory, exist_ok=True)
+        models = getattr(setting, "raw_model", setting.model)
+        if (epoch + 1) % 2 == 0 or (epoch + 1) == self.opt.epoch:
+            for key in models:
+                torch.save(models[key].state_dict(), os.path.join(save_directory, key + str(epoch + 1) + ".pt"))
+        if (epoch + 1) == self.opt.epoch:
+            for key in self.metric_name:
+                np.save(os.path.join(loss_directory, key + ".npy"), np.asarray(valid_log[key]))
+                np.save(os.path.join(loss_directory, "train_" + key + ".npy"), np.asarray(train_log[key]))

@@ -1,0 +1,189 @@
+"""`compute`: the step driver (reference: model_tool/processor.py:16-218), same method names.
+
+    forward_depth   processor.py:33-55      forward_pose   processor.py:58-136
+    image2warping   processor.py:139-163    compute_loss   processor.py:166-218
+
+With opt.fused (default) image2warping only forms the projection matrices and compute_loss runs ONE
+fused gfx950 kernel per scale (warp + SSIM/L1 + identity/noise + min); the identity losses, which do
+not depend on the scale, are evaluated once per step.  With opt.fused = False the reference's
+op-by-op sequence runs on the fine-grained kernels and every reference output key is populated
+(("warp_color", f, s), ...).  Results are identical between the two modes.
+"""
+import torch
+
+from model_layer import *  # noqa: F401,F403  (the reference does the same star-import, processor.py:11)
+from model_loss import *   # noqa: F401,F403
+from mdx import functional as F
+
+
+def _opt(opt, name, default):
+    return getattr(opt, name, default)
+
+
+class compute(object):
+    def __init__(self, opt, device):
+        self.opt = opt
+        self.device = device
+        self.num_pose_frames = len(opt.frame_ids) if opt.pose_frames == "all" else 2
+        self.fused = _opt(opt, "fused", True)
+        # "device": N(0,1) drawn on the GPU; "cpu": the reference's torch.randn on the host + H2D copy
+        # (processor.py:195) -- same stream of numbers as the reference for a given torch seed.
+        self.noise_mode = _opt(opt, "noise", "device")
+        self.amp = _opt(opt, "amp", "none")
+
+    # -- networks ---------------------------------------------------------------------------------
+    def _autocast(self):
+        enabled = self.amp == "bf16" and str(self.device).startswith("cuda")
+        return torch.autocast(device_type="cuda", dtype=torch.bfloat16, enabled=enabled)
+
+    def forward_depth(self, inputs, outputs, setting):
+        for key in inputs:
+            if torch.is_tensor(inputs[key]) and inputs[key].device != torch.device(self.device):
+                inputs[key] = inputs[key].to(self.device, non_blocking=True)
+        with self._autocast():
+            if self.opt.pose_type == "shared":
+                all_frames = torch.cat([inputs[("color_aug", f, 0)] for f in self.opt.frame_ids])
+                feats = setting.model["encoder"](all_frames)
+                feats = [torch.split(f, self.opt.batch) for f in feats]
+                outputs["features"] = feats
+                for index, frame_id in enumerate(self.opt.frame_ids):
+                    outputs.update({frame_id: [f[index] for f in feats]})
+                outputs.update(setting.model["decoder"](outputs[0]))
+            else:  # "separate" and "posecnn": one image through the depth network
+                outputs["features"] = setting.model["encoder"](inputs[("color_aug", 0, 0)])
+                outputs.update(setting.model["decoder"](outputs["features"]))
+        return inputs, outputs
+
+    def forward_pose(self, inputs, outputs, setting):
+        opt = self.opt
+        with self._autocast():
+            if self.num_pose_frames == 2:
+                for frame_id in opt.frame_ids[1:]:
+                    if frame_id == "s":
+                        continue
+                    first, second = (frame_id, 0) if frame_id < 0 else (0, frame_id)
+                    if opt.pose_type == "shared":
+                        pose_inputs = [outputs[first], outputs[second]]
+                    else:
+                        pose_inputs = torch.cat([inputs[("color_aug", first, 0)], inputs[("color_aug", second, 0)]], 1)
+                        if opt.pose_type == "separate":
+                            pose_inputs = [setting.model["pose_encoder"](pose_inputs)]
+                    axisangle, translation = setting.model["pose_decoder"](pose_inputs)
+                    outputs[("R", frame_id, 0)] = axisangle
+                    outputs[("T", frame_id, 0)] = translation
+                    outputs[("c2c", frame_id, 0)] = param2matrix(
+                        axisangle=axisangle[:, 0].float(), translation=translation[:, 0].float(),
+                        invert=(frame_id < 0))
+            else:
+                frames = [f for f in opt.frame_ids if f != "s"]
+                if opt.pose_type == "shared":
+                    axisangle, translation = setting.model["pose_decoder"]([outputs[f] for f in frames])
+                else:
+                    all_frames = torch.cat([inputs[("color_aug", f, 0)] for f in frames], 1)
+                    if opt.pose_type == "separate":
+                        all_frames = [setting.model["pose_encoder"](all_frames)]
+                    axisangle, translation = setting.model["pose_decoder"](all_frames)
+                for index, frame_id in enumerate(opt.frame_ids[1:]):
+                    if frame_id != "s":
+                        outputs[("R", frame_id, 0)] = axisangle
+                        outputs[("T", frame_id, 0)] = translation
+                        outputs[("c2c", frame_id, 0)] = param2matrix(
+                            axisangle=axisangle[:, index].float(), translation=translation[:, index].float())
+        return inputs, outputs
+
+    # -- geometry ---------------------------------------------------------------------------------
+    def _transformation(self, inputs, outputs, frame_id, depth_fn):
+        opt = self.opt
+        if frame_id == "s":
+            return inputs["stereo"]
+        if opt.pose_type in ["shared", "separate"]:
+            return outputs[("c2c", frame_id, 0)]
+        # posecnn (processor.py:153-157): translation scaled by the mean inverse depth
+        axisangle, translation = outputs[("R", frame_id, 0)], outputs[("T", frame_id, 0)]
+        depth = depth_fn()
+        mean_inv_depth = (1 / depth).mean(3, True).mean(2, True)
+        return param2matrix(axisangle[:, 0].float(), translation[:, 0].float() * mean_inv_depth[:, 0], (frame_id < 0))
+
+    def _depth(self, outputs, scale):
+        disp = interpolate(outputs[("disp", scale)].float(), self.opt.height, self.opt.width, "bilinear", False)
+        return disparity2depth(disp, self.opt.min_depth, self.opt.max_depth)[1]
+
+    def image2warping(self, inputs, outputs, setting):
+        opt = self.opt
+        K = inputs[("K", 0)]
+        for scale in opt.scales:
+            depth = None
+            if not self.fused:
+                depth = self._depth(outputs, scale)
+                outputs[("depth", 0, scale)] = depth
+            Ps = []
+            for frame_id in opt.frame_ids[1:]:
+                T = self._transformation(inputs, outputs, frame_id, lambda: self._depth(outputs, scale))
+                if self.fused:
+                    Ps.append(F.compose_projection(K, T))
+                else:
+                    cam = setting.inv_projection[0](depth, inputs[("inv_K", 0)])
+                    grid = setting.for_projection[0](cam, K, T)
+                    outputs[("warp_color", frame_id, scale)] = grid_sample(
+                        inputs[("color", frame_id, 0)], grid, "border", True)
+            if self.fused:
+                outputs[("P", scale)] = torch.stack(Ps)
+                if opt.pose_type != "posecnn":   # P does not depend on the scale: share it
+                    for s in opt.scales:
+                        outputs[("P", s)] = outputs[("P", scale)]
+                    break
+        return inputs, outputs
+
+    # -- loss -------------------------------------------------------------------------------------
+    def _noise(self, shape):
+        if self.noise_mode == "cpu":
+            return torch.randn(shape).to(self.device)
+        return torch.randn(shape, device=self.device)
+
+    def compute_loss(self, inputs, outputs, setting):
+        opt = self.opt
+        target = inputs[("color", 0, 0)]
+        sources = [inputs[("color", f, 0)] for f in opt.frame_ids[1:]]
+        S = len(sources)
+        B, _, H, W = target.shape
+        automask = bool(opt.use_automasking)
+        total_loss = 0
+        ident = None
+        if self.fused and automask:
+            ident = F.identity_loss(target, sources)          # once per step (scale-independent)
+        for scale in opt.scales:
+            disp = outputs[("disp", scale)].float()
+            color = inputs[("color", 0, scale)]
+            if self.fused:
+                noise = self._noise((B, S, H, W)) if automask else None
+                if ("noise", scale) in inputs:                 # injected (parity tests)
+                    noise = inputs[("noise", scale)]
+                res = F.photometric_scale(disp, outputs[("P", scale)], target, sources, inputs[("inv_K", 0)],
+                                          ident, noise, automask=automask, min_depth=opt.min_depth,
+                                          max_depth=opt.max_depth, need_depth=(scale == 0))
+                mean_min = res["sum"][0] / float(B * H * W)
+                outputs[("automask", scale)] = res["idx"]
+                if res["depth"] is not None:
+                    outputs[("depth", 0, scale)] = res["depth"]
+            else:
+                reprojection_loss = torch.cat([setting.loss["reprojection"](
+                    outputs[("warp_color", f, scale)], target) for f in opt.frame_ids[1:]], 1)
+                if automask:
+                    identity_loss = torch.cat([setting.loss["reprojection"](s, target) for s in sources], 1)
+                    noise = inputs[("noise", scale)] if ("noise", scale) in inputs else self._noise(identity_loss.shape)
+                    identity_loss = identity_loss + 0.00001 * noise
+                    combined_loss = torch.cat((identity_loss, reprojection_loss), dim=1)
+                else:
+                    combined_loss = reprojection_loss
+                if combined_loss.shape[1] == 1:
+                    to_optimise = combined_loss
+                else:
+                    to_optimise, idxs = torch.min(combined_loss, dim=1)
+                    outputs[("automask", scale)] = idxs
+                mean_min = to_optimise.mean()
+            smooth_loss = setting.loss["edge_aware"](disp=disp, color=color)
+            scale_loss = mean_min + opt.disp_smoothness * smooth_loss / (2 ** scale)
+            total_loss = total_loss + scale_loss
+        total_loss = total_loss / len(opt.scales)
+        outputs["loss"] = total_loss
+        return outputs

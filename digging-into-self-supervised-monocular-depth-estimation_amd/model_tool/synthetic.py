@@ -1,0 +1,55 @@
+"""Synthetic stand-in for the KITTI datasets (reference contract: model_loader/kitti_mono.py:258-375,
+kitti_stereo.py:168-306): same dictionary keys, shapes and dtypes, no files.  Used by bench.py and the
+tests -- the container and the GPU box hold no KITTI data."""
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+
+def make_K(height, width):
+    """Normalised KITTI intrinsics scaled to the image (kitti_stereo.py:236-246 form) + pinv."""
+    K = np.array([[0.58, 0, 0.5, 0], [0, 1.92, 0.5, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=np.float32)
+    K[0, :] *= width
+    K[1, :] *= height
+    return torch.from_numpy(K), torch.from_numpy(np.linalg.pinv(K).astype(np.float32))
+
+
+class SyntheticKITTI(Dataset):
+    def __init__(self, length, frame_ids, height, width, num_scales=4, seed=0, gt_size=(375, 1242)):
+        self.length, self.frame_ids = length, list(frame_ids)
+        self.height, self.width, self.num_scales = height, width, num_scales
+        self.seed, self.gt_size = seed, gt_size
+
+    def __len__(self):
+        return self.length
+
+    def __getitem__(self, index):
+        g = torch.Generator().manual_seed(self.seed * 1000003 + index)
+        inputs = {}
+        base = torch.rand(3, self.height // 8, self.width // 8, generator=g)
+        base = torch.nn.functional.interpolate(base[None], size=(self.height, self.width), mode="bilinear",
+                                               align_corners=False)[0]
+        for k, f in enumerate(self.frame_ids):
+            shift = 0 if f == 0 else (3 * k)
+            img = torch.roll(base, shifts=shift, dims=2) + 0.05 * torch.rand(3, self.height, self.width, generator=g)
+            img = img.clamp(0, 1)
+            for s in range(self.num_scales):
+                im = img if s == 0 else torch.nn.functional.avg_pool2d(img[None], 2 ** s)[0]
+                inputs[("color", f, s)] = im
+                inputs[("color_aug", f, s)] = im
+        K, invK = make_K(self.height, self.width)
+        for s in range(self.num_scales):
+            Ks = K.clone()
+            Ks[0, :] /= 2 ** s
+            Ks[1, :] /= 2 ** s
+            inputs[("K", s)] = Ks
+            inputs[("inv_K", s)] = torch.from_numpy(np.linalg.pinv(Ks.numpy()).astype(np.float32))
+        if "s" in self.frame_ids:
+            T = torch.eye(4)
+            T[0, 3] = 0.1
+            inputs["stereo"] = T
+        gt = torch.zeros(1, *self.gt_size)
+        m = torch.rand(1, *self.gt_size, generator=g) < 0.05
+        gt[m] = 1 + 79 * torch.rand(int(m.sum()), generator=g)
+        inputs[("depth", 0)] = gt
+        return inputs

@@ -1,0 +1,171 @@
+/*
+ * mdx.h -- C-ABI of the MI355X (gfx950) photometric hot path: libmdx_hip.so
+ *
+ * Drop-in boundary for the self-supervised depth training step of
+ * russellgeum/Digging-into-Self-Supervised-Monocular-Depth-Estimation:
+ *   model_tool/processor.py:139-163  compute.image2warping
+ *   model_tool/processor.py:166-218  compute.compute_loss
+ *   model_layer/warp.py:12-39,193-269, model_loss/model_loss.py:11-116 (the ops those two call)
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory (hipMalloc / a torch CUDA tensor's
+ *     data_ptr) unless the parameter is named host_*;
+ *   - float32, contiguous, NCHW planar; indices uint8;
+ *   - the caller allocates every input, output and workspace; the library never allocates, frees or
+ *     keeps a pointer after return; outputs are fully overwritten;
+ *   - kernels are enqueued on `stream` (a hipStream_t, NULL = default stream) and the call returns
+ *     without synchronising; re-entrant, no global mutable state;
+ *   - return 0 on success, a negative mdx_status otherwise (never throws, never aborts).
+ *
+ * Numerics: every per-pixel result reproduces the reference's CPU path (PyTorch ATen, CPU) bit for
+ * bit -- see DESIGN.md "pinned operation orders"; reductions and gradients agree to <= 1e-4 rel.
+ */
+#ifndef MDX_H
+#define MDX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDX_VERSION 100
+#define MDX_MAX_SRC 4
+
+typedef enum mdx_status {
+    MDX_OK = 0,
+    MDX_ERR_BAD_SHAPE = -1,       /* non-positive size, S out of range, h/w not H>>k, W or H < 4 */
+    MDX_ERR_NULL_POINTER = -2,    /* a required pointer is NULL */
+    MDX_ERR_WORKSPACE = -3,       /* workspace missing or too small */
+    MDX_ERR_LAUNCH = -4,          /* hipGetLastError() after launch was not hipSuccess */
+    MDX_ERR_UNSUPPORTED = -5,     /* flag/mode combination not implemented */
+    MDX_ERR_MISALIGNED = -6       /* pointer not 4-byte (float) / 8-byte (workspace) aligned */
+} mdx_status;
+
+/* flags */
+#define MDX_FLAG_AUTOMASK 1u       /* channels [ident(0..S-1), reproj(0..S-1)] (processor.py:186-196) */
+#define MDX_FLAG_UPSAMPLE_PREMUL 2u /* ATen's small-output bilinear kernel (H+W <= 128); set by mdx_desc_init */
+
+/* Problem descriptor of one scale of the step. */
+typedef struct mdx_desc {
+    int32_t B, H, W;      /* images, full resolution (opt.height, opt.width) */
+    int32_t h, w;         /* disparity resolution of this scale: outputs[("disp", s)] is [B,1,h,w] */
+    int32_t S;            /* number of source frames: len(opt.frame_ids) - 1, 1..MDX_MAX_SRC */
+    uint32_t flags;
+    float disp_a, disp_b; /* scaled_disp = disp_a + disp_b*disp (warp.py:34-37), f32-rounded */
+} mdx_desc;
+
+/* S source images, each [B,3,H,W] (inputs[("color", frame_id, 0)], order of opt.frame_ids[1:]) */
+typedef struct mdx_sources {
+    const float *img[MDX_MAX_SRC];
+} mdx_sources;
+
+/* Fills a descriptor; computes disp_a/disp_b from (min_depth, max_depth) exactly as
+ * warp.py:34-37 does (Python doubles, rounded to f32), and sets MDX_FLAG_UPSAMPLE_PREMUL. */
+int mdx_desc_init(mdx_desc *d, int B, int H, int W, int h, int w, int S, int automask,
+                  double min_depth, double max_depth);
+
+int mdx_version(void);
+const char *mdx_status_string(int status);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused path (what the training step runs)
+ * ---------------------------------------------------------------------------------------- */
+
+/* P[b] = (K[b] @ T[b])[:3,:]   replaces warp.py:260.  K,T [B,4,4] -> P [B,3,4]. */
+int mdx_compose_projection(const float *K, const float *T, int B, float *P, void *stream);
+
+/* Identity (auto-mask) losses, hoisted out of the scale loop because they do not depend on the
+ * scale: ident[b,f] = ReprojectionLoss(color_f, target)   replaces processor.py:187-191.
+ * target [B,3,H,W], ident out [B,S,H,W] (noise NOT added here). */
+int mdx_identity_loss(const mdx_desc *d, const float *target, const mdx_sources *src, float *ident,
+                      void *stream);
+
+size_t mdx_photometric_workspace_bytes(const mdx_desc *d);
+
+/* One scale of image2warping + compute_loss, forward   replaces processor.py:141-162,172-204,212.
+ *   disp [B,1,h,w]; target [B,3,H,W]; invK [B,4,4]; P [S,B,3,4]; ident [B,S,H,W]; noise [B,S,H,W]
+ *   (ident/noise only with MDX_FLAG_AUTOMASK; noise is the N(0,1) draw of processor.py:195).
+ * Outputs: idx [B,H,W] uint8 (arg-min channel, torch.min's first-minimum rule);
+ *          loss_sum [1] float = sum over B,H,W of to_optimise (divide by B*H*W for .mean());
+ * optional (NULL to skip): to_opt [B,H,W]; depth [B,1,H,W]; warp [S,B,3,H,W]; reproj [B,S,H,W]. */
+int mdx_photometric_fwd(const mdx_desc *d, const float *disp, const float *target,
+                        const mdx_sources *src, const float *invK, const float *P,
+                        const float *ident, const float *noise, uint8_t *idx, float *loss_sum,
+                        float *to_opt, float *depth, float *warp, float *reproj, void *workspace,
+                        size_t workspace_bytes, void *stream);
+
+/* Backward of the above for d(loss)/d(to_optimise[b,y,x]) = g_const * (*g_dev) on every pixel
+ * (g_dev may be NULL = 1).  Recomputes the warp; needs only the inputs and idx.
+ * Outputs: gdisp [B,1,h,w]; gP [S,B,3,4] (d loss / d P; chain to T with K^T outside). */
+int mdx_photometric_bwd(const mdx_desc *d, const float *disp, const float *target,
+                        const mdx_sources *src, const float *invK, const float *P,
+                        const uint8_t *idx, float g_const, const float *g_dev, float *gdisp,
+                        float *gP, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Edge-aware smoothness   replaces model_loss.py:77-88,112-115 (processor.py:208).
+ * disp [B,1,h,w], color [B,3,h,w] -> loss [1]; gdisp (optional) = d loss / d disp for unit upstream.
+ * normalize = 1: SmoothLoss (disp / (mean_HW(disp) + 1e-7) first); 0: EdgeAwareSmooth on disp as given. */
+size_t mdx_smooth_workspace_bytes(int B, int h, int w);
+int mdx_smooth_loss(int B, int h, int w, const float *disp, const float *color, int normalize, float *loss,
+                    float *gdisp, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fine-grained ops behind the reference's model_layer / model_loss API (each differentiable)
+ * ---------------------------------------------------------------------------------------- */
+
+/* interpolate(x, H, W, "bilinear", align_corners=False)   warp.py:18-20.  x [BC,h,w] -> [BC,H,W] */
+int mdx_interpolate_bilinear_fwd(const float *x, int BC, int h, int w, float *out, int H, int W,
+                                 void *stream);
+int mdx_interpolate_bilinear_bwd(const float *gout, int BC, int H, int W, float *gin, int h, int w,
+                                 void *stream);
+
+/* disparity2depth   warp.py:29-39.  sd/depth may be NULL.  bwd: gdisp = gsd*b + gdepth*(-b*depth^2) */
+int mdx_disparity2depth_fwd(const float *disp, size_t n, double min_depth, double max_depth,
+                            float *sd, float *depth, void *stream);
+int mdx_disparity2depth_bwd(const float *disp, const float *gsd, const float *gdepth, size_t n,
+                            double min_depth, double max_depth, float *gdisp, void *stream);
+
+/* Depth2PointCloud.forward   warp.py:237-246.  depth [B,1,H,W], invK [B,4,4] -> cam [B,4,HW] */
+int mdx_backproject_fwd(const float *depth, const float *invK, int B, int H, int W, float *cam,
+                        void *stream);
+int mdx_backproject_bwd(const float *gcam, const float *invK, int B, int H, int W, float *gdepth,
+                        void *stream);
+
+/* PointCloud2Pixel.forward   warp.py:259-269, with P = (K@T)[:3].  cam [B,4,HW] -> grid [B,H,W,2]
+ * bwd: ggrid -> gcam [B,4,HW] (row 3 zero) and gP [B,3,4]. workspace: mdx_project_workspace_bytes */
+size_t mdx_project_workspace_bytes(int B, int H, int W);
+int mdx_project_fwd(const float *cam, const float *P, int B, int H, int W, float eps, float *grid,
+                    void *stream);
+int mdx_project_bwd(const float *cam, const float *P, const float *ggrid, int B, int H, int W,
+                    float eps, float *gcam, float *gP, void *workspace, size_t workspace_bytes,
+                    void *stream);
+
+/* grid_sample(img, grid, "border", align_corners=True), bilinear   warp.py:12-14.
+ * img [B,C,Hi,Wi], grid [B,Ho,Wo,2] -> out [B,C,Ho,Wo];  bwd -> ggrid (gimg optional, atomics) */
+int mdx_grid_sample_border_fwd(const float *img, const float *grid, int B, int C, int Hi, int Wi,
+                               int Ho, int Wo, float *out, void *stream);
+int mdx_grid_sample_border_bwd(const float *img, const float *grid, const float *gout, int B, int C,
+                               int Hi, int Wi, int Ho, int Wo, float *ggrid, float *gimg,
+                               void *stream);
+
+/* ReprojectionLoss.forward   model_loss.py:97-103 (SSIM 28-41).  pred,target [B,3,H,W] -> [B,1,H,W]
+ * bwd: gout [B,1,H,W] -> gpred [B,3,H,W] (gtarget optional) */
+int mdx_reprojection_loss_fwd(const float *pred, const float *target, int B, int H, int W,
+                              float *out, void *stream);
+int mdx_reprojection_loss_bwd(const float *pred, const float *target, const float *gout, int B,
+                              int H, int W, float *gpred, float *gtarget, void *stream);
+/* SSIM.forward alone   model_loss.py:28-41.  x,y [BC,H,W] -> [BC,H,W] */
+int mdx_ssim_fwd(const float *x, const float *y, int BC, int H, int W, float *out, void *stream);
+
+/* identity+noise, concat, per-pixel min   processor.py:194-204.  ident/noise/reproj [B,S,H,W]
+ * -> combined [B,C,H,W] (optional), to_opt [B,H,W], idx [B,H,W] uint8 */
+int mdx_min_automask_fwd(const float *ident, const float *noise, const float *reproj, int B, int S,
+                         int H, int W, int automask, float *combined, float *to_opt, uint8_t *idx,
+                         void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDX_H */
