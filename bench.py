@@ -1,0 +1,289 @@
+#!/usr/bin/env python3
+"""bench.py -- training throughput of the self-supervised depth step on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = BASELINE.json configs[1]: ResNet-18 depth encoder/decoder + separate ResNet-18 pose network
+(two source frames), the fused photometric loss at 4 scales, backward, Adam -- fp32, 192x640, batch 12 per
+GPU, synthetic KITTI-shaped inputs resident in HBM.  Data parallel: one process per GPU, DDP over RCCL;
+per-GPU work is fixed (weak scaling).  Prints ONE JSON line on rank 0.
+
+Extra objects in the line:
+  roofline      the dominant hand-written kernel (photometric forward or backward, whichever takes longer),
+                algorithmic bytes per launch (SURVEY 8d formula) / HIP-event launch time / 8 TB/s
+  cpu_baseline  the same step on the host cores: torch-CPU networks + the CPU oracle for the loss path
+                (kind "port"), on a bounded sample (batch 4, configs[0])
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def make_opt(batch, height=192, width=640, frame_ids=(0, -1, 1), num_layers=18, amp="none", workers=0):
+    o = types.SimpleNamespace()
+    o.dataset, o.datatype, o.datapath, o.splits = "synthetic", "kitti_eigen_zhou", "", ""
+    o.batch, o.height, o.width = batch, height, width
+    o.scales, o.frame_ids = [0, 1, 2, 3], list(frame_ids)
+    o.min_depth, o.max_depth, o.disp_smoothness = 0.1, 100.0, 1e-3
+    o.use_automasking, o.pose_type, o.pose_frames = True, "separate", "pair"
+    o.num_layers, o.weight_init = num_layers, False          # random init: no checkpoints offline
+    o.learning_rate, o.scheduler_step, o.epoch, o.save = 1e-4, 15, 1, "bench"
+    o.num_workers, o.synthetic_length = workers, 2 * batch
+    o.fused, o.noise, o.amp, o.channels_last = True, "device", amp, False
+    return o
+
+
+def one_batch(setting, device):
+    batch = next(iter(setting.train_dataloader))
+    return {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+
+def alg_bytes(B, H, W, S, scale, bwd=False):
+    """target RGB + S source RGB (each unique byte once) + uint8 index + low-res disparity."""
+    n_lo = B * (H >> scale) * (W >> scale)
+    return B * H * W * (12 + 12 * S + 1) + n_lo * (8 if bwd else 4)
+
+
+def time_kernels(device, B, H, W, S, reps=20):
+    """Average launch duration of the fused forward / backward kernels over the 4 scales, measured with
+    HIP events on the stream the kernels are enqueued on (torch's current stream)."""
+    import ctypes as C
+    from mdx import _lib
+    from mdx import functional as F
+    lib = _lib.lib()
+    g = torch.Generator(device="cpu").manual_seed(0)
+    tgt = torch.rand(B, 3, H, W, generator=g).to(device)
+    srcs = [torch.rand(B, 3, H, W, generator=g).to(device) for _ in range(S)]
+    from model_tool.synthetic import make_K
+    K, invK = make_K(H, W)
+    K, invK = K.to(device).repeat(B, 1, 1), invK.to(device).repeat(B, 1, 1)
+    T = torch.eye(4, device=device).repeat(B, 1, 1)
+    T[:, :3, 3] = 0.02 * torch.randn(B, 3, generator=g).to(device)
+    P = torch.stack([F.compose_projection(K, T) for _ in range(S)])
+    ident = F.identity_loss(tgt, srcs)
+    noise = torch.randn(B, S, H, W, generator=g).to(device)
+    idx = torch.empty(B, H, W, dtype=torch.uint8, device=device)
+    src = _lib.make_sources(srcs)
+    res = {}
+    for name in ("fwd", "bwd"):
+        tot_ms, tot_bytes, launches = 0.0, 0, 0
+        for s in range(4):
+            h, w = H >> s, W >> s
+            disp = torch.rand(B, 1, h, w, generator=g).to(device)
+            d = _lib.make_desc(B, H, W, h, w, S, True, 0.1, 100.0)
+            nws = lib.mdx_photometric_workspace_bytes(C.byref(d))
+            ws = torch.empty(nws // 8 + 1, dtype=torch.float64, device=device)
+            gdisp = torch.empty_like(disp)
+            gP = torch.empty(S, B, 3, 4, device=device)
+
+            def fwd():
+                _lib.check(lib.mdx_photometric_fwd(
+                    C.byref(d), _lib.ptr(disp), _lib.ptr(tgt), C.byref(src), _lib.ptr(invK), _lib.ptr(P),
+                    _lib.ptr(ident), _lib.ptr(noise), _lib.ptr(idx, torch.uint8), None, None, None, None, None,
+                    _lib.ptr(ws, torch.float64), C.c_size_t(nws), _lib.stream()), "fwd")
+
+            def bwd():
+                _lib.check(lib.mdx_photometric_bwd(
+                    C.byref(d), _lib.ptr(disp), _lib.ptr(tgt), C.byref(src), _lib.ptr(invK), _lib.ptr(P),
+                    _lib.ptr(idx, torch.uint8), C.c_float(1e-6), None, _lib.ptr(gdisp), _lib.ptr(gP),
+                    _lib.ptr(ws, torch.float64), C.c_size_t(nws), _lib.stream()), "bwd")
+            fwd()
+            fn = fwd if name == "fwd" else bwd
+            for _ in range(3):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            e1.synchronize()
+            tot_ms += e0.elapsed_time(e1) / reps
+            tot_bytes += alg_bytes(B, H, W, S, s, bwd=(name == "bwd"))
+            launches += 1
+        res[name] = {"ms": tot_ms / launches, "bytes": tot_bytes / launches}
+    return res
+
+
+def cpu_baseline(batch=4, steps=2):
+    """The same training step on the host: torch-CPU networks + the CPU oracle for the loss path."""
+    from oracle import oracle as orc
+    from model_layer import ResnetEncoder, DepthDecoder, PoseDecoder, param2matrix
+    from model_tool.synthetic import SyntheticKITTI
+    H, W, S = 192, 640, 2
+    torch.manual_seed(0)
+    enc, pose_enc = ResnetEncoder(18, False), ResnetEncoder(18, False, 2)
+    dec, pose_dec = DepthDecoder(enc.num_ch_enc), PoseDecoder(pose_enc.num_ch_enc, 1, 2)
+    params = [p for m in (enc, dec, pose_enc, pose_dec) for p in m.parameters()]
+    optim = torch.optim.Adam(params, 1e-4)
+    ds = SyntheticKITTI(batch, [0, -1, 1], H, W)
+    items = [ds[i] for i in range(batch)]
+    inputs = {k: torch.stack([it[k] for it in items]) for k in items[0]}
+    tgt = inputs[("color", 0, 0)].numpy()
+    srcs = [inputs[("color", f, 0)].numpy() for f in (-1, 1)]
+    invK = inputs[("inv_K", 0)].numpy()
+    n = batch * H * W
+
+    class OracleScale(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, disp, P, noise):
+            out = orc.photometric_fwd(disp.numpy(), tgt, srcs, invK, P.numpy(), noise)
+            ctx.save_for_backward(disp, P)
+            ctx.idx = out["idx"]
+            return torch.tensor(out["sum"] / n, dtype=torch.float32)
+
+        @staticmethod
+        def backward(ctx, g):
+            disp, P = ctx.saved_tensors
+            gd, gP = orc.photometric_bwd(disp.numpy(), tgt, srcs, invK, P.numpy(), ctx.idx, float(g) / n)
+            return torch.from_numpy(gd), torch.from_numpy(gP), None
+
+    class OracleSmooth(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, disp, color):
+            v, g = orc.smooth_loss(disp.numpy(), color.numpy(), need_grad=True)
+            ctx.g = torch.from_numpy(g)
+            return torch.tensor(v, dtype=torch.float32)
+
+        @staticmethod
+        def backward(ctx, g):
+            return ctx.g * g, None
+
+    rng = np.random.RandomState(0)
+    t0 = None
+    for step in range(steps + 1):
+        if step == 1:
+            t0 = time.perf_counter()
+        feats = enc(inputs[("color_aug", 0, 0)])
+        disps = dec(feats)
+        Ps = []
+        for f in (-1, 1):
+            a, b = (f, 0) if f < 0 else (0, f)
+            pin = torch.cat([inputs[("color_aug", a, 0)], inputs[("color_aug", b, 0)]], 1)
+            aa, tr = pose_dec([pose_enc(pin)])
+            T = param2matrix(aa[:, 0], tr[:, 0], invert=(f < 0))
+            Ps.append(torch.matmul(inputs[("K", 0)], T)[:, :3, :])
+        P = torch.stack(Ps)
+        loss = 0
+        for s in range(4):
+            noise = rng.randn(batch, S, H, W).astype(np.float32)
+            loss = loss + OracleScale.apply(disps[("disp", s)], P, noise)
+            loss = loss + 1e-3 * OracleSmooth.apply(disps[("disp", s)], inputs[("color", 0, s)]) / (2 ** s)
+        loss = loss / 4
+        optim.zero_grad()
+        loss.backward()
+        optim.step()
+    dt = time.perf_counter() - t0
+    return {"value": batch * steps / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "batch %d (configs[0]) x %d steps after 1 warm-up: torch-CPU nets + oracle loss path" % (batch, steps)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=12)
+    ap.add_argument("--amp", type=str, default="none", choices=["none", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    device = "cuda:%d" % local
+    if world > 1:
+        torch.distributed.init_process_group("nccl", device_id=torch.device(device))
+    importlib.import_module("digging-into-self-supervised-monocular-depth-estimation_amd")
+    from model_tool import setting, compute
+
+    torch.manual_seed(1234 + rank)
+    opt = make_opt(args.batch, amp=args.amp)
+    st = setting(opt, device)
+    cp = compute(opt, device)
+    st.set_train()
+    inputs = one_batch(st, device)
+    optim = st.optim["optimizer"]
+
+    def step():
+        outputs = {}
+        i, o = cp.forward_depth(inputs, outputs, st)
+        i, o = cp.forward_pose(i, o, st)
+        i, o = cp.image2warping(i, o, st)
+        o = cp.compute_loss(i, o, st)
+        optim.zero_grad(set_to_none=True)
+        o["loss"].backward()
+        optim.step()
+        return o["loss"]
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax[0])
+    loss_val = float(loss)
+
+    if rank == 0:
+        line = {
+            "metric": "images/sec training, KITTI 192x640 batch 12/GPU", "value": world * args.batch * args.steps / dt,
+            "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32" if args.amp == "none" else "bf16-nets/f32-loss", "data": "synthetic",
+            "config": {"workload": "configs[1]: kitti_eigen_zhou-shaped 192x640, batch %d/GPU, ResNet18 depth + "
+                                   "separate ResNet18 pose, frame_ids [0,-1,1], 4 scales, automask, Adam, fp32"
+                                   % args.batch,
+                       "global_batch": world * args.batch, "parallelism": "dp%d" % world},
+            "final_loss": loss_val,
+        }
+        if not args.no_roofline and world == 1:
+            k = time_kernels(device, args.batch, opt.height, opt.width, 2)
+            dom = max(k, key=lambda n: k[n]["ms"])
+            for n in k:
+                k[n]["GBs"] = k[n]["bytes"] / (k[n]["ms"] * 1e-3) / 1e9
+            line["roofline"] = {"kernel": "photometric_%s_kernel<2>" % dom, "bound": "hbm",
+                                "achieved": k[dom]["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": k[dom]["GBs"] / HBM_PEAK_GBS, "traffic": None,
+                                "launch_us": 1e3 * k[dom]["ms"], "alg_bytes_per_launch": k[dom]["bytes"]}
+            other = "fwd" if dom == "bwd" else "bwd"
+            line["roofline_other"] = {"kernel": "photometric_%s_kernel<2>" % other, "achieved": k[other]["GBs"],
+                                      "frac": k[other]["GBs"] / HBM_PEAK_GBS, "launch_us": 1e3 * k[other]["ms"],
+                                      "alg_bytes_per_launch": k[other]["bytes"]}
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

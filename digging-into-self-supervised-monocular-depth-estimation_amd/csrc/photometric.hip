@@ -531,7 +531,7 @@ MDX_EXPORT int mdx_photometric_fwd(const mdx_desc *d, const float *disp, const f
 {
     int rc = validate_desc(d);
     if (rc) return rc;
-    if (!disp || !target || !src || !invK || !P || !idx || !loss_sum) return MDX_ERR_NULL_POINTER;
+    if (!disp || !target || !src || !invK || !P || !idx) return MDX_ERR_NULL_POINTER;
     if ((d->flags & MDX_FLAG_AUTOMASK) && (!ident || !noise)) return MDX_ERR_NULL_POINTER;
     for (int f = 0; f < d->S; ++f)
         if (!src->img[f]) return MDX_ERR_NULL_POINTER;
@@ -542,7 +542,7 @@ MDX_EXPORT int mdx_photometric_fwd(const mdx_desc *d, const float *disp, const f
     a.ident = ident; a.noise = noise; a.idx = idx; a.to_opt = to_opt; a.depth = depth; a.warp = warp;
     a.reproj = reproj; a.partials = (double *)workspace;
     rc = launch_fwd<false>(a, (hipStream_t)stream);
-    if (rc) return rc;
+    if (rc || !loss_sum) return rc;   // loss_sum == NULL: leave the per-tile partials in the workspace
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream,
                        (const double *)workspace, (int)num_tiles(d), loss_sum);
     return check_launch();

@@ -87,7 +87,7 @@ class setting(object):
             dev_ids = [torch.device(self.device).index] if str(self.device).startswith("cuda") else None
             for key in list(self.model):
                 self.ddp[key] = DDP(self.model[key], device_ids=dev_ids, bucket_cap_mb=_opt(opt, "bucket_mb", 32),
-                                    gradient_as_bucket_view=True)
+                                    gradient_as_bucket_view=True, broadcast_buffers=False)
             self.raw_model = dict(self.model)
             self.model = dict(self.ddp)
             # attributes the step driver reads from the bare modules

@@ -88,7 +88,8 @@ size_t mdx_photometric_workspace_bytes(const mdx_desc *d);
  *   disp [B,1,h,w]; target [B,3,H,W]; invK [B,4,4]; P [S,B,3,4]; ident [B,S,H,W]; noise [B,S,H,W]
  *   (ident/noise only with MDX_FLAG_AUTOMASK; noise is the N(0,1) draw of processor.py:195).
  * Outputs: idx [B,H,W] uint8 (arg-min channel, torch.min's first-minimum rule);
- *          loss_sum [1] float = sum over B,H,W of to_optimise (divide by B*H*W for .mean());
+ *          loss_sum [1] float = sum over B,H,W of to_optimise (divide by B*H*W for .mean()); NULL skips
+ *          the finishing pass and leaves one double per tile at the start of the workspace;
  * optional (NULL to skip): to_opt [B,H,W]; depth [B,1,H,W]; warp [S,B,3,H,W]; reproj [B,S,H,W]. */
 int mdx_photometric_fwd(const mdx_desc *d, const float *disp, const float *target,
                         const mdx_sources *src, const float *invK, const float *P,
