@@ -66,8 +66,11 @@ def time_kernels(device, B, H, W, S, reps=20):
     from mdx import functional as F
     lib = _lib.lib()
     g = torch.Generator(device="cpu").manual_seed(0)
-    tgt = torch.rand(B, 3, H, W, generator=g).to(device)
-    srcs = [torch.rand(B, 3, H, W, generator=g).to(device) for _ in range(S)]
+    base = torch.nn.functional.interpolate(torch.rand(B, 3, H // 4, W // 4, generator=g), size=(H, W),
+                                           mode="bilinear", align_corners=False)
+    tgt = (base + 0.05 * torch.rand(B, 3, H, W, generator=g)).clamp(0, 1).to(device)
+    srcs = [(torch.roll(base, 3 * (k + 1), 3) + 0.05 * torch.rand(B, 3, H, W, generator=g)).clamp(0, 1).to(device)
+            for k in range(S)]
     from model_tool.synthetic import make_K
     K, invK = make_K(H, W)
     K, invK = K.to(device).repeat(B, 1, 1), invK.to(device).repeat(B, 1, 1)
@@ -83,7 +86,10 @@ def time_kernels(device, B, H, W, S, reps=20):
         tot_ms, tot_bytes, launches = 0.0, 0, 0
         for s in range(4):
             h, w = H >> s, W >> s
-            disp = torch.rand(B, 1, h, w, generator=g).to(device)
+            lo = torch.randn(B, 1, max(H // 32, 2), max(W // 32, 2), generator=g)   # network-like smooth field
+            disp = torch.sigmoid(torch.nn.functional.interpolate(lo, size=(h, w), mode="bilinear",
+                                                                 align_corners=False)).contiguous().to(device)
+            warp = torch.empty(S, B, 3, H, W, device=device)
             d = _lib.make_desc(B, H, W, h, w, S, True, 0.1, 100.0)
             nws = lib.mdx_photometric_workspace_bytes(C.byref(d))
             ws = torch.empty(nws // 8 + 1, dtype=torch.float64, device=device)
@@ -93,13 +99,13 @@ def time_kernels(device, B, H, W, S, reps=20):
             def fwd():
                 _lib.check(lib.mdx_photometric_fwd(
                     C.byref(d), _lib.ptr(disp), _lib.ptr(tgt), C.byref(src), _lib.ptr(invK), _lib.ptr(P),
-                    _lib.ptr(ident), _lib.ptr(noise), _lib.ptr(idx, torch.uint8), None, None, None, None, None,
-                    _lib.ptr(ws, torch.float64), C.c_size_t(nws), _lib.stream()), "fwd")
+                    _lib.ptr(ident), _lib.ptr(noise), _lib.ptr(idx, torch.uint8), None, None, None, _lib.ptr(warp),
+                    None, _lib.ptr(ws, torch.float64), C.c_size_t(nws), _lib.stream()), "fwd")
 
             def bwd():
                 _lib.check(lib.mdx_photometric_bwd(
                     C.byref(d), _lib.ptr(disp), _lib.ptr(tgt), C.byref(src), _lib.ptr(invK), _lib.ptr(P),
-                    _lib.ptr(idx, torch.uint8), C.c_float(1e-6), None, _lib.ptr(gdisp), _lib.ptr(gP),
+                    _lib.ptr(idx, torch.uint8), _lib.ptr(warp), C.c_float(1e-6), None, _lib.ptr(gdisp), _lib.ptr(gP),
                     _lib.ptr(ws, torch.float64), C.c_size_t(nws), _lib.stream()), "bwd")
             fwd()
             fn = fwd if name == "fwd" else bwd

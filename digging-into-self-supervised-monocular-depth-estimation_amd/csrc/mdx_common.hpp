@@ -29,6 +29,13 @@ static inline int validate_desc(const mdx_desc *d)
     return MDX_OK;
 }
 
+#include "mdx_divtable.inc"
+// is x/b == the 3-instruction constant division for every normal x?  (tools/gen_divtable.c)
+static inline bool div_verified(int b)
+{
+    return b >= 2 && b < 4096 && ((MDX_DIV_OK[b >> 5] >> (b & 31)) & 1u);
+}
+
 static inline dim3 tile_grid(const mdx_desc *d)
 {
     return dim3((d->W + TX - 1) / TX, (d->H + TY - 1) / TY, d->B);

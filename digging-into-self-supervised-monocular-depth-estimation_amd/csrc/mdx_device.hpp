@@ -81,12 +81,50 @@ MDX_DEV void pixel_ray(const float *__restrict__ invK, float x, float y, float r
 }
 
 // ---------------------------------------------------------------------------------------------
+// Correctly rounded division by a constant in three instructions instead of the ~10 of the generic
+// IEEE sequence:  q = x*r;  e = fma(-b, q, x);  q' = fma(e, r, q)   with r = RN(1/b).
+// tools/check_constdiv.c proves q' == x/b bit for bit for EVERY finite float x (subnormals
+// included) for b = 9 and 3 (and the benchmark sizes' W-1, H-1); tools/gen_divtable.c proves it for all
+// normal x for every integer 2 <= b < 4096 (csrc/mdx_divtable.inc).  Precondition: x finite.
+// ---------------------------------------------------------------------------------------------
+MDX_DEV float div_by_const(float x, float b, float r)
+{
+    const float q = x * r;
+    const float e = __builtin_fmaf(-b, q, x);
+    return __builtin_fmaf(e, r, q);
+}
+MDX_DEV float div9(float x) { return div_by_const(x, 9.0f, 1.0f / 9.0f); }
+MDX_DEV float div3(float x) { return div_by_const(x, 3.0f, 1.0f / 3.0f); }
+
+// division by the run-time constants W-1 / H-1: fast form only when the host found the divisor in the
+// verified table, and only for normal finite x; everything else takes the IEEE divide
+struct NormDiv { float b, r; bool fast; };
+
+MDX_DEV NormDiv make_normdiv(int n_minus_1, bool fast)
+{
+    NormDiv d;
+    d.b = (float)n_minus_1;
+    d.r = 1.0f / d.b;
+    d.fast = fast;
+    return d;
+}
+
+MDX_DEV float div_norm(float x, const NormDiv &d)
+{
+    const float ax = fabsf(x);
+    if (d.fast && ax > 1e-30f && ax < 3.0e38f) return div_by_const(x, d.b, d.r);
+    return x / d.b;
+}
+
+// ---------------------------------------------------------------------------------------------
 // A5  PointCloud2Pixel (warp.py:261-268)
 // ---------------------------------------------------------------------------------------------
 struct Proj { float u, v, z, gx, gy; };
 
-MDX_DEV Proj project_point(const float *__restrict__ P, float X0, float X1, float X2, float X3, int H,
-                           int W, float eps)
+struct Norm2 { NormDiv w, h; };
+
+MDX_DEV Proj project_point(const float *__restrict__ P, float X0, float X1, float X2, float X3,
+                           const Norm2 &nd, float eps)
 {
     float q[3];
 #pragma unroll
@@ -100,8 +138,8 @@ MDX_DEV Proj project_point(const float *__restrict__ P, float X0, float X1, floa
     p.z = q[2] + eps;
     p.u = q[0] / p.z;
     p.v = q[1] / p.z;
-    float nx = p.u / (float)(W - 1);
-    float ny = p.v / (float)(H - 1);
+    float nx = div_norm(p.u, nd.w);
+    float ny = div_norm(p.v, nd.h);
     p.gx = (nx - 0.5f) * 2.0f;
     p.gy = (ny - 0.5f) * 2.0f;
     return p;
@@ -137,15 +175,25 @@ MDX_DEV Tap make_tap(float gx, float gy, int H, int W)
 struct Corners { float nw, ne, sw, se; };
 
 // out-of-range corners read as 0 (ATen's masked gather); x0,y0 are always in range after clipping
+// The two taps of a row are adjacent floats: ONE 8-byte load per row (global_load_dwordx2; 4-byte
+// alignment is enough on gfx950) instead of two dword gathers -- the memory pipeline of a CU is paced
+// by load INSTRUCTIONS here, not by bytes.  The pair is anchored at min(x0, W-2) so it never leaves
+// the row; the row below is clamped to H-1 and zeroed when it is out of range.  Needs W >= 2.
+typedef float float2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+
 MDX_DEV Corners load_corners(const float *__restrict__ img, int H, int W, const Tap &t)
 {
-    bool xe = t.x0 + 1 < W, ys = t.y0 + 1 < H;
-    const float *p = img + (size_t)t.y0 * W + t.x0;
+    const int xl = t.x0 < W - 1 ? t.x0 : W - 2;
+    const bool shifted = xl != t.x0;            // x0 == W-1: the east taps are out of range
+    const bool ys = t.y0 + 1 < H;
+    const int y1 = ys ? t.y0 + 1 : t.y0;
+    const float2_a4 top = *reinterpret_cast<const float2_a4 *>(img + (size_t)t.y0 * W + xl);
+    const float2_a4 bot = *reinterpret_cast<const float2_a4 *>(img + (size_t)y1 * W + xl);
     Corners c;
-    c.nw = p[0];
-    c.ne = xe ? p[1] : 0.f;
-    c.sw = ys ? p[W] : 0.f;
-    c.se = (xe && ys) ? p[W + 1] : 0.f;
+    c.nw = shifted ? top.y : top.x;
+    c.ne = shifted ? 0.f : top.y;
+    c.sw = ys ? (shifted ? bot.y : bot.x) : 0.f;
+    c.se = ys ? (shifted ? 0.f : bot.y) : 0.f;
     return c;
 }
 
@@ -171,7 +219,7 @@ MDX_DEV float pool9(const float v[9])
     float s = v[0];
 #pragma unroll
     for (int k = 1; k < 9; ++k) s = s + v[k];
-    return s / 9.0f;
+    return div9(s);
 }
 
 struct TargetStats { float mu, e2, mu2; };   // mu_y, pool(y*y), mu_y*mu_y
@@ -229,8 +277,8 @@ MDX_DEV float reprojection_combine(const float ssim[3], const float ad[3])
 {
     float l1 = (ad[0] + ad[1]) + ad[2];
     float ss = (ssim[0] + ssim[1]) + ssim[2];
-    l1 = l1 / 3.0f;
-    ss = ss / 3.0f;
+    l1 = div3(l1);
+    ss = div3(ss);
     float a = 0.85f * ss, b = 0.15f * l1;
     return a + b;
 }

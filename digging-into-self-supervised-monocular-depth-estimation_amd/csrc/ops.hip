@@ -82,15 +82,18 @@ __global__ __launch_bounds__(NT) void backproject_bwd_kernel(const float *__rest
 }
 
 __global__ __launch_bounds__(NT) void project_fwd_kernel(const float *__restrict__ cam, const float *__restrict__ P, int B,
-                                                         int H, int W, float eps, float *__restrict__ grid)
+                                                         int H, int W, float eps, float *__restrict__ grid, bool fw, bool fh)
 {
+    Norm2 nd;
+    nd.w = make_normdiv(W - 1, fw);
+    nd.h = make_normdiv(H - 1, fh);
     const size_t HW = (size_t)H * W;
     const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
     if (i >= (size_t)B * HW) return;
     const int b = (int)(i / HW);
     const size_t p = i % HW;
     const float *c = cam + (size_t)b * 4 * HW + p;
-    const Proj pr = project_point(P + b * 12, c[0], c[HW], c[2 * HW], c[3 * HW], H, W, eps);
+    const Proj pr = project_point(P + b * 12, c[0], c[HW], c[2 * HW], c[3 * HW], nd, eps);
     grid[i * 2] = pr.gx;
     grid[i * 2 + 1] = pr.gy;
 }
@@ -101,6 +104,9 @@ __global__ __launch_bounds__(NT) void project_bwd_kernel(const float *__restrict
                                                          float eps, float *__restrict__ gcam, float *__restrict__ partP)
 {
     __shared__ float s_red[NT / 64][12];
+    Norm2 nd;
+    nd.w = make_normdiv(W - 1, false);
+    nd.h = make_normdiv(H - 1, false);
     const size_t HW = (size_t)H * W;
     const int b = blockIdx.y;
     const size_t p = (size_t)blockIdx.x * NT + threadIdx.x;
@@ -111,7 +117,7 @@ __global__ __launch_bounds__(NT) void project_bwd_kernel(const float *__restrict
         const float *c = cam + (size_t)b * 4 * HW + p;
         const float *Pb = P + b * 12;
         const float X[4] = {c[0], c[HW], c[2 * HW], c[3 * HW]};
-        const Proj pr = project_point(Pb, X[0], X[1], X[2], X[3], H, W, eps);
+        const Proj pr = project_point(Pb, X[0], X[1], X[2], X[3], nd, eps);
         const float gu = ggrid[((size_t)b * HW + p) * 2] * (2.0f / (float)(W - 1));
         const float gv = ggrid[((size_t)b * HW + p) * 2 + 1] * (2.0f / (float)(H - 1));
         const float iz = 1.0f / pr.z;
@@ -375,7 +381,7 @@ MDX_EXPORT int mdx_project_fwd(const float *cam, const float *P, int B, int H, i
     MDX_REQUIRE(cam && P && grid, MDX_ERR_NULL_POINTER);
     MDX_REQUIRE(B > 0 && H > 1 && W > 1, MDX_ERR_BAD_SHAPE);
     hipLaunchKernelGGL(project_fwd_kernel, grid1d((size_t)B * H * W), dim3(NT), 0, (hipStream_t)stream, cam, P, B, H,
-                       W, eps, grid);
+                       W, eps, grid, div_verified(W - 1), div_verified(H - 1));
     return check_launch();
 }
 

@@ -9,7 +9,8 @@ import os
 
 import torch
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "libmdx_hip.so")
+LIB_PATH = os.environ.get("MDX_LIB") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                     "libmdx_hip.so")   # MDX_LIB: developer override (kernel A/B builds)
 MAX_SRC = 4
 FLAG_AUTOMASK = 1
 _lib = None

@@ -87,7 +87,11 @@ class _PhotometricScale(torch.autograd.Function):
         loss_sum = torch.empty(1, device=dev, dtype=torch.float32)
         to_opt = torch.empty(B, H, W, device=dev, dtype=torch.float32) if cfg.get("need_to_opt") else None
         depth = torch.empty(B, 1, H, W, device=dev, dtype=torch.float32) if cfg.get("need_depth") else None
-        warp = torch.empty(S, B, 3, H, W, device=dev, dtype=torch.float32) if cfg.get("need_warp") else None
+        # training keeps the warped colours for the backward kernel (35 MB per scale at B=12: cheaper to
+        # re-read than to re-warp the 2-pixel halo); cfg["save_warp"] = False restores the recompute path
+        keep_warp = cfg.get("save_warp", True) and (disp.requires_grad or P.requires_grad)
+        warp = torch.empty(S, B, 3, H, W, device=dev, dtype=torch.float32) \
+            if (cfg.get("need_warp") or keep_warp) else None
         reproj = torch.empty(B, S, H, W, device=dev, dtype=torch.float32) if cfg.get("need_reproj") else None
         nws = lib().mdx_photometric_workspace_bytes(C.byref(d))
         ws = _ws(nws, dev)
@@ -98,6 +102,7 @@ class _PhotometricScale(torch.autograd.Function):
             ptr(warp, optional=True), ptr(reproj, optional=True), ptr(ws, torch.float64), C.c_size_t(nws),
             stream()), "mdx_photometric_fwd")
         ctx.save_for_backward(disp, P, target, invK, idx, *sources)
+        ctx.warp = warp if keep_warp else None
         ctx.cfg = dict(cfg)
         ctx.mark_non_differentiable(*[t for t in (idx, to_opt, depth, warp, reproj) if t is not None])
         return (loss_sum, idx, to_opt, depth, warp, reproj)
@@ -119,14 +124,14 @@ class _PhotometricScale(torch.autograd.Function):
         ws = _ws(nws, dev)
         check(lib().mdx_photometric_bwd(
             C.byref(d), ptr(disp), ptr(target), C.byref(src), ptr(invK), ptr(P), ptr(idx, torch.uint8),
-            C.c_float(1.0), ptr(g_dev), ptr(gdisp), ptr(gP), ptr(ws, torch.float64), C.c_size_t(nws),
-            stream()), "mdx_photometric_bwd")
+            ptr(ctx.warp, optional=True), C.c_float(1.0), ptr(g_dev), ptr(gdisp), ptr(gP), ptr(ws, torch.float64),
+            C.c_size_t(nws), stream()), "mdx_photometric_bwd")
         return (gdisp, gP, None, None, None, None, None) + (None,) * S
 
 
 def photometric_scale(disp, P, target, sources, invK, ident=None, noise=None, automask=True,
                       min_depth=0.1, max_depth=100.0, need_to_opt=False, need_depth=False,
-                      need_warp=False, need_reproj=False):
+                      need_warp=False, need_reproj=False, save_warp=True):
     """Fused warp + SSIM/L1 + min for one scale.
 
     disp [B,1,h,w] (grad), P [S,B,3,4] (grad), target [B,3,H,W], sources: list of S [B,3,H,W],
@@ -135,7 +140,8 @@ def photometric_scale(disp, P, target, sources, invK, ident=None, noise=None, au
     optional 'to_opt', 'depth', 'warp' ([S,B,3,H,W]), 'reproj' ([B,S,H,W]).
     """
     cfg = dict(automask=bool(automask), min_depth=float(min_depth), max_depth=float(max_depth),
-               need_to_opt=need_to_opt, need_depth=need_depth, need_warp=need_warp, need_reproj=need_reproj)
+               need_to_opt=need_to_opt, need_depth=need_depth, need_warp=need_warp, need_reproj=need_reproj,
+               save_warp=save_warp)
     out = _PhotometricScale.apply(disp, P, target, invK, ident, noise, cfg, *sources)
     return dict(zip(("sum", "idx", "to_opt", "depth", "warp", "reproj"), out))
 

@@ -46,6 +46,8 @@ typedef enum mdx_status {
 /* flags */
 #define MDX_FLAG_AUTOMASK 1u       /* channels [ident(0..S-1), reproj(0..S-1)] (processor.py:186-196) */
 #define MDX_FLAG_UPSAMPLE_PREMUL 2u /* ATen's small-output bilinear kernel (H+W <= 128); set by mdx_desc_init */
+#define MDX_FLAG_FASTDIV_W 4u      /* W-1 is in the verified constant-division table (set by mdx_desc_init) */
+#define MDX_FLAG_FASTDIV_H 8u      /* H-1 likewise */
 
 /* Problem descriptor of one scale of the step. */
 typedef struct mdx_desc {
@@ -98,12 +100,13 @@ int mdx_photometric_fwd(const mdx_desc *d, const float *disp, const float *targe
                         size_t workspace_bytes, void *stream);
 
 /* Backward of the above for d(loss)/d(to_optimise[b,y,x]) = g_const * (*g_dev) on every pixel
- * (g_dev may be NULL = 1).  Recomputes the warp; needs only the inputs and idx.
+ * (g_dev may be NULL = 1).  Needs only the inputs and idx; `warp` (optional, [S,B,3,H,W]) is the forward's
+ * warped-colour output -- when given the kernel reads it instead of re-warping the 2-pixel halo.
  * Outputs: gdisp [B,1,h,w]; gP [S,B,3,4] (d loss / d P; chain to T with K^T outside). */
 int mdx_photometric_bwd(const mdx_desc *d, const float *disp, const float *target,
                         const mdx_sources *src, const float *invK, const float *P,
-                        const uint8_t *idx, float g_const, const float *g_dev, float *gdisp,
-                        float *gP, void *workspace, size_t workspace_bytes, void *stream);
+                        const uint8_t *idx, const float *warp, float g_const, const float *g_dev,
+                        float *gdisp, float *gP, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Edge-aware smoothness   replaces model_loss.py:77-88,112-115 (processor.py:208).
  * disp [B,1,h,w], color [B,3,h,w] -> loss [1]; gdisp (optional) = d loss / d disp for unit upstream.
