@@ -124,12 +124,20 @@ def time_kernels(device, B, H, W, S, reps=20):
     return res
 
 
-def cpu_baseline(batch=4, steps=2):
+def cpu_baseline(batch=4, steps=3):
     """The same training step on the host: torch-CPU networks + the CPU oracle for the loss path."""
     from oracle import oracle as orc
     from model_layer import ResnetEncoder, DepthDecoder, PoseDecoder, param2matrix
     from model_tool.synthetic import SyntheticKITTI
     H, W, S = 192, 640, 2
+    # the GPU box gives one GPU's share of the host: 16 cores (gpurun); never oversubscribe
+    cores = max(1, min(16, len(os.sched_getaffinity(0))))
+    torch.set_num_threads(cores)
+    try:
+        import ctypes
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(cores)   # the oracle's OpenMP loops
+    except OSError:
+        pass
     torch.manual_seed(0)
     enc, pose_enc = ResnetEncoder(18, False), ResnetEncoder(18, False, 2)
     dec, pose_dec = DepthDecoder(enc.num_ch_enc), PoseDecoder(pose_enc.num_ch_enc, 1, 2)
