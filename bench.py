@@ -105,8 +105,8 @@ def time_kernels(device, B, H, W, S, reps=20):
             def bwd():
                 _lib.check(lib.mdx_photometric_bwd(
                     C.byref(d), _lib.ptr(disp), _lib.ptr(tgt), C.byref(src), _lib.ptr(invK), _lib.ptr(P),
-                    _lib.ptr(idx, torch.uint8), _lib.ptr(warp), C.c_float(1e-6), None, _lib.ptr(gdisp), _lib.ptr(gP),
-                    _lib.ptr(ws, torch.float64), C.c_size_t(nws), _lib.stream()), "bwd")
+                    _lib.ptr(idx, torch.uint8), _lib.ptr(warp), C.c_float(1e-6), None, None, None,
+                    _lib.ptr(ws, torch.float64), C.c_size_t(nws), _lib.stream()), "bwd")   # fused kernel alone
             fwd()
             fn = fwd if name == "fwd" else bwd
             for _ in range(3):
@@ -212,6 +212,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=12)
     ap.add_argument("--amp", type=str, default="none", choices=["none", "bf16"])
+    ap.add_argument("--channels-last", action="store_true", help="NHWC activations/weights for the conv nets")
+    ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark (MIOpen find mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -230,6 +232,8 @@ def main():
 
     torch.manual_seed(1234 + rank)
     opt = make_opt(args.batch, amp=args.amp)
+    opt.channels_last = args.channels_last
+    torch.backends.cudnn.benchmark = args.miopen_find
     st = setting(opt, device)
     cp = compute(opt, device)
     st.set_train()
@@ -283,12 +287,13 @@ def main():
             dom = max(k, key=lambda n: k[n]["ms"])
             for n in k:
                 k[n]["GBs"] = k[n]["bytes"] / (k[n]["ms"] * 1e-3) / 1e9
-            line["roofline"] = {"kernel": "photometric_%s_kernel<2>" % dom, "bound": "hbm",
+            kname = {"fwd": "mdx::photometric_fwd_kernel<2, false>", "bwd": "mdx::photometric_bwd_kernel<2, true>"}
+            line["roofline"] = {"kernel": kname[dom], "bound": "hbm",
                                 "achieved": k[dom]["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": k[dom]["GBs"] / HBM_PEAK_GBS, "traffic": None,
                                 "launch_us": 1e3 * k[dom]["ms"], "alg_bytes_per_launch": k[dom]["bytes"]}
             other = "fwd" if dom == "bwd" else "bwd"
-            line["roofline_other"] = {"kernel": "photometric_%s_kernel<2>" % other, "achieved": k[other]["GBs"],
+            line["roofline_other"] = {"kernel": kname[other], "achieved": k[other]["GBs"],
                                       "frac": k[other]["GBs"] / HBM_PEAK_GBS, "launch_us": 1e3 * k[other]["ms"],
                                       "alg_bytes_per_launch": k[other]["bytes"]}
         if not args.no_cpu_baseline and world == 1:

@@ -244,18 +244,22 @@ MDX_EXPORT int mdx_photometric_bwd(const mdx_desc *d, const float *disp, const f
 {
     int rc = validate_desc(d);
     if (rc) return rc;
-    if (!disp || !target || !invK || !P || !idx || !gdisp || !gP) return MDX_ERR_NULL_POINTER;
+    if (!disp || !target || !invK || !P || !idx) return MDX_ERR_NULL_POINTER;
+    if ((gdisp == nullptr) != (gP == nullptr)) return MDX_ERR_NULL_POINTER;
     if ((rc = check_sources(d, src))) return rc;
     if (!workspace || workspace_bytes < ws_total(d)) return MDX_ERR_WORKSPACE;
     if (!aligned(workspace, 8) || !aligned(target, 16) || (warp && !aligned(warp, 16))) return MDX_ERR_MISALIGNED;
     hipStream_t st = (hipStream_t)stream;
-    const bool same = (d->h == d->H && d->w == d->W);
+    // gdisp == gP == NULL: run the fused kernel only and leave its raw outputs (per-tile d(P) partials, the
+    // full-resolution disparity gradient) in the workspace -- used to time that kernel in isolation
+    const bool raw = gdisp == nullptr;
+    const bool same = !raw && (d->h == d->H && d->w == d->W);
     BwdArgs a = {};
     a.d = *d; a.disp = disp; a.target = target; a.src = *src; a.invK = invK; a.P = P; a.idx = idx;
     a.warp = warp; a.g_const = g_const; a.g_dev = g_dev;
     a.partP = (float *)((char *)workspace + ws_off_partP(d));
     a.gup = same ? gdisp : (float *)((char *)workspace + ws_off_gup(d));
-    if ((rc = launch_photometric_bwd(a, st))) return rc;
+    if ((rc = launch_photometric_bwd(a, st)) || raw) return rc;
     const dim3 grid = tile_grid(d);
     if ((rc = launch_finish_gP(a.partP, d->S, d->B, (int)(grid.x * grid.y), g_const, g_dev, gP, st))) return rc;
     if (!same) rc = launch_upsample_bwd(a.gup, d->B, d->H, d->W, gdisp, d->h, d->w, st);

@@ -102,7 +102,8 @@ int mdx_photometric_fwd(const mdx_desc *d, const float *disp, const float *targe
 /* Backward of the above for d(loss)/d(to_optimise[b,y,x]) = g_const * (*g_dev) on every pixel
  * (g_dev may be NULL = 1).  Needs only the inputs and idx; `warp` (optional, [S,B,3,H,W]) is the forward's
  * warped-colour output -- when given the kernel reads it instead of re-warping the 2-pixel halo.
- * Outputs: gdisp [B,1,h,w]; gP [S,B,3,4] (d loss / d P; chain to T with K^T outside). */
+ * Outputs: gdisp [B,1,h,w]; gP [S,B,3,4] (d loss / d P; chain to T with K^T outside).  Passing NULL for BOTH
+ * runs the fused kernel alone and leaves its raw per-tile outputs in the workspace (timing aid). */
 int mdx_photometric_bwd(const mdx_desc *d, const float *disp, const float *target,
                         const mdx_sources *src, const float *invK, const float *P,
                         const uint8_t *idx, const float *warp, float g_const, const float *g_dev,
