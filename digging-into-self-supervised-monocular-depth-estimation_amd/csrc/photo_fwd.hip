@@ -66,7 +66,10 @@ MDX_DEV float upsample_staged(const float *s_d, const DispRegion &r, const mdx_d
 }
 
 template <int S, bool IDENT>
-__global__ __launch_bounds__(NT) void photometric_fwd_kernel(FwdArgs a)
+#ifndef MDX_FWD_WAVES
+#define MDX_FWD_WAVES 5
+#endif
+__global__ __launch_bounds__(NT, MDX_FWD_WAVES) void photometric_fwd_kernel(FwdArgs a)
 {
     __shared__ float s_t[3][FY][FX];
     __shared__ float s_x[S][3][FY][FX];
