@@ -288,9 +288,17 @@ def main():
             for n in k:
                 k[n]["GBs"] = k[n]["bytes"] / (k[n]["ms"] * 1e-3) / 1e9
             kname = {"fwd": "mdx::photometric_fwd_kernel<2, false>", "bwd": "mdx::photometric_bwd_kernel<2, true>"}
+            # HBM-side bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE are
+            # collected in separate runs of tools/kbench.py; see profiles/r01_kernel_pmc.txt), null if absent
+            traffic = {}
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_kernel_pmc.json")))
+                traffic = {n: pmc[kname[n]]["traffic_bytes"] for n in kname if kname[n] in pmc}
+            except (OSError, ValueError, KeyError):
+                pass
             line["roofline"] = {"kernel": kname[dom], "bound": "hbm",
                                 "achieved": k[dom]["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": k[dom]["GBs"] / HBM_PEAK_GBS, "traffic": None,
+                                "frac": k[dom]["GBs"] / HBM_PEAK_GBS, "traffic": traffic.get(dom),
                                 "launch_us": 1e3 * k[dom]["ms"], "alg_bytes_per_launch": k[dom]["bytes"]}
             other = "fwd" if dom == "bwd" else "bwd"
             line["roofline_other"] = {"kernel": kname[other], "achieved": k[other]["GBs"],

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Averages rocprofv3 --pmc counter_collection.csv files per hand-written kernel.
+    python tools/pmc_summary.py out.txt dir1 [dir2 ...]"""
+import collections
+import csv
+import glob
+import os
+import sys
+
+
+def main():
+    dst, dirs = sys.argv[1], sys.argv[2:]
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for d in dirs:
+        for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if "mdx::photometric" in r["Kernel_Name"]:
+                    agg[r["Kernel_Name"].replace("void ", "")[:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    lines = ["# rocprofv3 --pmc, mean per launch (tools/kbench.py: B=12, 192x640, S=2, all four scales)"]
+    for k in sorted(agg):
+        lines.append(k)
+        for c in sorted(agg[k]):
+            v = agg[k][c]
+            lines.append("    %-32s %16.0f   (n=%d)" % (c, sum(v) / len(v), len(v)))
+        d = agg[k]
+        if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+            fe, wr = sum(d["FETCH_SIZE"]) / len(d["FETCH_SIZE"]), sum(d["WRITE_SIZE"]) / len(d["WRITE_SIZE"])
+            lines.append("    HBM-side traffic: FETCH_SIZE %.1f MB as reported (x2 = %.1f MB with the gfx950 wide-read "
+                         "correction of MI355X_MICROARCH.md; these kernels mix 16-byte streams and 8-byte gathers, "
+                         "so the true value lies between) + WRITE_SIZE %.1f MB" % (fe / 1024, 2 * fe / 1024, wr / 1024))
+    open(dst, "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+    # machine-readable traffic per launch for bench.py's roofline.traffic (bytes; FETCH_SIZE doubled as the
+    # microarchitecture guide prescribes for gfx950, WRITE_SIZE as reported; both are in KiB)
+    import json
+    out = {}
+    for k, d in agg.items():
+        if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+            fe, wr = sum(d["FETCH_SIZE"]) / len(d["FETCH_SIZE"]), sum(d["WRITE_SIZE"]) / len(d["WRITE_SIZE"])
+            out[k.split("(")[0]] = {"fetch_size_kib": fe, "write_size_kib": wr, "traffic_bytes": (2 * fe + wr) * 1024}
+    json.dump(out, open(os.path.splitext(dst)[0] + ".json", "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
