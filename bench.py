@@ -223,10 +223,15 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
+    local = local % torch.cuda.device_count()          # rehearsal: several ranks may share one GPU
     torch.cuda.set_device(local)
     device = "cuda:%d" % local
     if world > 1:
-        torch.distributed.init_process_group("nccl", device_id=torch.device(device))
+        backend = os.environ.get("MDX_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm; "gloo" only to rehearse
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=torch.device(device))
+        else:
+            torch.distributed.init_process_group(backend)
     importlib.import_module("digging-into-self-supervised-monocular-depth-estimation_amd")
     from model_tool import setting, compute
 
@@ -268,7 +273,7 @@ def main():
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax[0])
-    loss_val = float(loss)
+    loss_val = float(loss.detach())
 
     if rank == 0:
         line = {
