@@ -1,0 +1,136 @@
+"""KITTI raw datasets (reference: model_loader/kitti_mono.py:258-375, kitti_stereo.py:168-306).
+
+One implementation, `KITTIDataset`, produces the dictionary contract the step driver consumes:
+    ("color", f, s), ("color_aug", f, s)  [3, H>>s, W>>s] float32 in [0,1]      f in frame_ids, s in 0..3
+    ("K", s), ("inv_K", s)                [4,4]
+    ("depth", 0)                          [1,375,1242] velodyne ground truth (0 = no return)
+    "stereo"                              [4,4]  (only with "s" in frame_ids)
+`KITTIMonoDataset_v2` / `KITTIMonoStereoDataset` keep the reference constructor signatures.
+
+Differences, stated: Pillow >= 10 (Image.LANCZOS instead of the removed ANTIALIAS); colour jitter is drawn per
+sample (the reference draws it once per dataset through a removed torchvision API); `k_mode="reference_mono"`
+reproduces the mono loader's intrinsics exactly (row 1 scaled by WIDTH and floored, kitti_mono.py:326-327 ->
+[[371,0,320],[0,1228,320]] at 640x192), `k_mode="scaled"` is the stereo loader's form (kitti_stereo.py:236-246).
+"""
+import os
+import random
+
+import numpy as np
+import torch
+from PIL import Image, ImageEnhance
+from torch.utils.data import Dataset
+
+from model_utility import point2depth, resize_nearest
+
+SIDE_MAP = {"2": 2, "3": 3, "l": 2, "r": 3}
+K_NORM = np.array([[0.58, 0, 0.5, 0], [0, 1.92, 0.5, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=np.float32)
+
+
+def to_tensor(img):
+    return torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).float().div_(255.0)
+
+
+class ColorJitter(object):
+    """brightness / contrast / saturation in [0.8,1.2], hue in [-0.1,0.1], random order -- one draw per sample."""
+
+    def __init__(self, rng):
+        self.b, self.c, self.s = (rng.uniform(0.8, 1.2) for _ in range(3))
+        self.h = rng.uniform(-0.1, 0.1)
+        self.order = rng.sample(range(4), 4)
+
+    def __call__(self, img):
+        for op in self.order:
+            if op == 0:
+                img = ImageEnhance.Brightness(img).enhance(self.b)
+            elif op == 1:
+                img = ImageEnhance.Contrast(img).enhance(self.c)
+            elif op == 2:
+                img = ImageEnhance.Color(img).enhance(self.s)
+            else:
+                hsv = np.array(img.convert("HSV"), dtype=np.uint8)
+                hsv[..., 0] = (hsv[..., 0].astype(np.int16) + int(self.h * 255)) % 256
+                img = Image.fromarray(hsv, "HSV").convert("RGB")
+        return img
+
+
+class KITTIDataset(Dataset):
+    def __init__(self, datapath, filename, is_training, frame_ids, height=192, width=640, ext=".jpg", scale=4,
+                 k_mode="reference_mono", gt_size=(375, 1242), load_depth=True):
+        if height % 32 != 0 or width % 32 != 0:
+            raise ValueError("(H, W) must be multiples of 32; KITTI sizes are (192, 640) or (320, 1024)")
+        self.datapath, self.filename, self.is_training = datapath, list(filename), is_training
+        self.frame_ids, self.height, self.width = list(frame_ids), height, width
+        self.ext = ext if ext.startswith(".") else "." + ext
+        self.scale, self.k_mode, self.gt_size, self.load_depth = scale, k_mode, gt_size, load_depth
+
+    def __len__(self):
+        return len(self.filename)
+
+    def image_path(self, folder, frame_index, side):
+        return os.path.join(self.datapath, folder, "image_0{}/data".format(SIDE_MAP[side]),
+                            "{:010d}{}".format(frame_index, self.ext))
+
+    def load_image(self, folder, frame_index, side, do_flip):
+        with open(self.image_path(folder, frame_index, side), "rb") as f:
+            with Image.open(f) as img:
+                image = img.convert("RGB")
+        return image.transpose(Image.FLIP_LEFT_RIGHT) if do_flip else image
+
+    def load_point(self, folder, frame_index, side, do_flip):
+        calib_path = os.path.join(self.datapath, folder.split("/")[0])
+        velo = os.path.join(self.datapath, folder, "velodyne_points/data/{:010d}.bin".format(int(frame_index)))
+        depth = resize_nearest(point2depth(calib_path, velo, SIDE_MAP[side]), self.gt_size)
+        if do_flip:
+            depth = np.fliplr(depth)
+        return torch.from_numpy(np.ascontiguousarray(depth[None], dtype=np.float32))
+
+    def intrinsics(self, scale):
+        K = K_NORM.copy()
+        if self.k_mode == "reference_mono":         # kitti_mono.py:326-327, bug included on purpose
+            K[0, :] = K[0, :] * self.width // (2 ** scale)
+            K[1, :] = K[1, :] * self.width // (2 ** scale)
+        else:                                       # kitti_stereo.py:240-241 (float floor division too)
+            K[0, :] = K[0, :] * self.width // (2 ** scale)
+            K[1, :] = K[1, :] * self.height // (2 ** scale)
+        return torch.from_numpy(K), torch.from_numpy(np.linalg.pinv(K))
+
+    def __getitem__(self, index):
+        do_color = self.is_training and random.random() > 0.5
+        do_flip = self.is_training and random.random() > 0.5
+        line = self.filename[index].split()
+        folder, key_frame, side = line[0], int(line[1]), line[2]
+        jitter = ColorJitter(random) if do_color else (lambda x: x)
+        other = {"r": "l", "l": "r", "2": "3", "3": "2"}[side]
+        out = {}
+        for frame_id in self.frame_ids:
+            if frame_id == "s":
+                image = self.load_image(folder, key_frame, other, do_flip)
+            else:
+                image = self.load_image(folder, key_frame + frame_id, side, do_flip)
+            for s in range(self.scale):
+                small = image.resize((self.width // (2 ** s), self.height // (2 ** s)), Image.LANCZOS)
+                out[("color", frame_id, s)] = to_tensor(small)
+                out[("color_aug", frame_id, s)] = to_tensor(jitter(small))
+        if self.load_depth:
+            out[("depth", 0)] = self.load_point(folder, key_frame, side, do_flip)
+        for s in range(self.scale):
+            out[("K", s)], out[("inv_K", s)] = self.intrinsics(s)
+        if "s" in self.frame_ids:                    # kitti_stereo.py:249-256
+            T = np.eye(4, dtype=np.float32)
+            baseline_sign = -1 if do_flip else 1
+            side_sign = -1 if SIDE_MAP[side] == 2 else 1
+            T[0, 3] = side_sign * baseline_sign * 0.1
+            out["stereo"] = torch.from_numpy(T)
+        return out
+
+
+class KITTIMonoDataset_v2(KITTIDataset):
+    """reference signature: (datapath, filename, is_training, frame_ids, height, width, ext, scale)."""
+
+    def __init__(self, datapath, filename, is_training, frame_ids, height=192, width=640, ext="jpg", scale=4):
+        super().__init__(datapath, filename, is_training, frame_ids, height, width, ext, scale, k_mode="reference_mono")
+
+
+class KITTIMonoStereoDataset(KITTIDataset):
+    def __init__(self, datapath, filename, is_training, frame_ids, height=192, width=640, ext="jpg", scale=4):
+        super().__init__(datapath, filename, is_training, frame_ids, height, width, ext, scale, k_mode="scaled")

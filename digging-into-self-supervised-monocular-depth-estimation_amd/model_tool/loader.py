@@ -45,9 +45,11 @@ class setting(object):
             dataset = SyntheticKITTI(length, opt.frame_ids, opt.height, opt.width, len(opt.scales),
                                      seed=0 if is_training else 1)
         else:
-            raise NotImplementedError(
-                "dataset %r: the KITTI file loaders (reference model_loader/kitti_mono.py, kitti_stereo.py) are "
-                "the next scope row (SURVEY 8f N2); this build ships the synthetic contract only" % opt.dataset)
+            from model_loader import KITTIMonoDataset_v2, KITTIMonoStereoDataset
+            from model_utility import readlines
+            names = readlines(os.path.join(opt.splits, opt.datatype, "{}_files.txt".format(split)))
+            cls = KITTIMonoDataset_v2 if opt.dataset == "kitti_mono" else KITTIMonoStereoDataset
+            dataset = cls(opt.datapath, names, is_training, opt.frame_ids, opt.height, opt.width, ".jpg", len(opt.scales))
         sampler = None
         if self.distributed:
             sampler = DistributedSampler(dataset, self.world_size, self.rank, shuffle=shuffle, drop_last=True)

@@ -1,0 +1,98 @@
+"""Split-file, calibration and velodyne helpers (reference: model_utility.py:18-197), numpy only.
+
+    readlines          model_utility.py:18-22      read_calib / read_cam2cam   model_utility.py:59-104
+    read_velodyne_points  model_utility.py:108-115  point2depth                 model_utility.py:128-197
+"""
+import os
+
+import numpy as np
+
+
+def readlines(datapath):
+    with open(datapath, "r") as f:
+        return f.read().splitlines()
+
+
+def read_calib(path):
+    """KITTI calibration file -> {key: float array | string} (reference read_velo2cam, model_utility.py:84-104)."""
+    data = {}
+    with open(path, "r") as f:
+        for line in f:
+            if ":" not in line:
+                continue
+            key, value = line.split(":", 1)
+            value = value.strip()
+            try:
+                data[key] = np.array([float(x) for x in value.split()])
+            except ValueError:
+                data[key] = value
+    return data
+
+
+read_velo2cam = read_calib
+
+
+def read_cam2cam(path):
+    """4x4 intrinsics of the left / right colour cameras (model_utility.py:59-80)."""
+    data = read_calib(path)
+    out = []
+    for key in ("P_rect_02", "P_rect_03"):
+        K = np.eye(4, dtype=np.float32)
+        K[:3, :3] = data[key].reshape(3, 4)[:3, :3]
+        out.append(K)
+    return out[0], out[1]
+
+
+def read_velodyne_points(filename):
+    points = np.fromfile(filename, dtype=np.float32).reshape(-1, 4)
+    points[:, 3] = 1.0
+    return points
+
+
+def point2depth(calib_path, point_path, cam=2, vel_depth=False):
+    """Projects a velodyne scan into camera `cam` -> sparse depth map [h, w] (model_utility.py:128-197).
+    Where several points fall on one pixel the nearest one wins (the reference's Counter loop, vectorised)."""
+    cam2cam = read_calib(os.path.join(calib_path, "calib_cam_to_cam.txt"))
+    velo2cam = read_calib(os.path.join(calib_path, "calib_velo_to_cam.txt"))
+    velo2cam = np.hstack((velo2cam["R"].reshape(3, 3), velo2cam["T"][..., np.newaxis]))
+    velo2cam = np.vstack((velo2cam, np.array([0, 0, 0, 1.0])))
+    im_shape = cam2cam["S_rect_02"][::-1].astype(np.int32)
+    R_cam2rect = np.eye(4)
+    R_cam2rect[:3, :3] = cam2cam["R_rect_00"].reshape(3, 3)
+    P_rect = cam2cam["P_rect_0" + str(cam)].reshape(3, 4)
+    P_velo2im = P_rect @ R_cam2rect @ velo2cam
+    velo = read_velodyne_points(point_path)
+    velo = velo[velo[:, 0] >= 0, :]
+    pts = (P_velo2im @ velo.T).T
+    pts[:, :2] = pts[:, :2] / pts[:, 2][..., np.newaxis]
+    if vel_depth:
+        pts[:, 2] = velo[:, 0]
+    pts[:, 0] = np.round(pts[:, 0]) - 1
+    pts[:, 1] = np.round(pts[:, 1]) - 1
+    ok = (pts[:, 0] >= 0) & (pts[:, 1] >= 0) & (pts[:, 0] < im_shape[1]) & (pts[:, 1] < im_shape[0])
+    pts = pts[ok]
+    depth = np.zeros(tuple(im_shape[:2]))
+    xs, ys = pts[:, 0].astype(np.int64), pts[:, 1].astype(np.int64)
+    # last write wins for unique pixels (as the reference's fancy-index assignment); duplicates -> minimum
+    depth[ys, xs] = pts[:, 2]
+    flat = ys * depth.shape[1] + xs
+    uniq, counts = np.unique(flat, return_counts=True)
+    dup = np.isin(flat, uniq[counts > 1])
+    if dup.any():
+        mins = np.full(depth.size, np.inf)
+        np.minimum.at(mins, flat[dup], pts[dup, 2])
+        sel = np.isfinite(mins)
+        depth.reshape(-1)[sel] = mins[sel]
+    depth[depth < 0] = 0
+    return depth
+
+
+def resize_nearest(depth, out_hw):
+    """skimage.transform.resize(depth, out_hw, order=0, preserve_range=True, mode='constant') equivalent."""
+    h, w = depth.shape
+    H, W = out_hw
+    if (h, w) == (H, W):
+        return depth
+    ys = np.clip(np.round((np.arange(H) + 0.5) * h / H - 0.5).astype(np.int64), 0, h - 1)
+    xs = np.clip(np.round((np.arange(W) + 0.5) * w / W - 0.5).astype(np.int64), 0, w - 1)
+    return depth[ys][:, xs]

@@ -94,3 +94,37 @@ def test_training_step_runs_and_learns(G):
     assert all(np.isfinite(losses)), losses
     assert losses[-1] < losses[0], losses
     assert o[("automask", 0)].dtype == torch.uint8 and o[("depth", 0, 0)].shape == (2, 1, 64, 96)
+
+
+def test_kitti_tree_training_and_eigen_style_evaluation(G, tmp_path):
+    """N2 + N3 on a synthetic KITTI-raw tree: `setting` with dataset='kitti_mono' feeds the step; the evaluation
+    protocol (reference model_test.py:61-119) runs end to end with random weights."""
+    import importlib
+    import os
+    import fake_kitti
+    from model_tool import setting, compute
+    bench = importlib.import_module("bench")
+    names = fake_kitti.make(str(tmp_path), n_frames=6)
+    os.makedirs(os.path.join(str(tmp_path), "splits", "fake"))
+    for split in ("train", "val", "test"):
+        open(os.path.join(str(tmp_path), "splits", "fake", split + "_files.txt"), "w").write("\n".join(names) + "\n")
+    opt = bench.make_opt(2, height=192, width=640)
+    opt.dataset, opt.datapath, opt.splits, opt.datatype = "kitti_mono", str(tmp_path), os.path.join(str(tmp_path), "splits"), "fake"
+    torch.manual_seed(0)
+    st, cp = setting(opt, G.DEV), compute(opt, G.DEV)
+    st.set_train()
+    inputs = next(iter(st.train_dataloader))
+    o = {}
+    i, o = cp.forward_depth(inputs, o, st)
+    i, o = cp.forward_pose(i, o, st)
+    i, o = cp.image2warping(i, o, st)
+    o = cp.compute_loss(i, o, st)
+    o["loss"].backward()
+    assert np.isfinite(float(o["loss"].detach()))
+    from model_loss import compute_depth_metric
+    m = compute_depth_metric(i, o, "torch")
+    assert all(np.isfinite(float(v)) for v in m)
+    import model_test
+    res = model_test.inference(opt, encoder=st.raw_model["encoder"], decoder=st.raw_model["decoder"])
+    assert set(res) == set(model_test.METRICS) and all(np.isfinite(v) for v in res.values())
+    assert 0 <= res["a1"] <= res["a2"] <= res["a3"] <= 1
