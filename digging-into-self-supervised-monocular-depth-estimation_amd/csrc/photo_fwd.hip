@@ -21,7 +21,8 @@
 namespace mdx {
 
 constexpr int NPIX = (FX * FY + NT - 1) / NT;   // tile+halo pixels per thread in stage 1 (3)
-constexpr int ROWS = TY / (NT / 64);            // output rows per thread in stage 2 (2)
+constexpr int ROWS = TY / (NT / 64);            // output rows per thread in stage 2 (2): ADJACENT rows, so that
+                                                // the two 3x3 windows share two of their three LDS rows and products
 
 struct HaloPx { int ly, lx, px, py; bool valid, interior; };
 
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(NT, MDX_FWD_WAVES) void photometric_fwd_kernel(FwdA
     if (!IDENT && automask) {   // issue the per-pixel loads first: their latency hides under the SSIM math
 #pragma unroll
         for (int q = 0; q < ROWS; ++q) {
-            const int py = y0 + (tid >> 6) + q * (NT / 64);
+            const int py = y0 + ROWS * (tid >> 6) + q;
             const bool valid = px < W && py < H;
 #pragma unroll
             for (int f = 0; f < S; ++f) {
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(NT, MDX_FWD_WAVES) void photometric_fwd_kernel(FwdA
     }
 #pragma unroll
     for (int q = 0; q < ROWS; ++q) {
-        const int r = (tid >> 6) + q * (NT / 64);
+        const int r = ROWS * (tid >> 6) + q;
         const int py = y0 + r;
         const bool valid = px < W && py < H;
         const size_t p = (size_t)(valid ? py : 0) * W + (valid ? px : 0);
