@@ -171,7 +171,8 @@ def _synth(B, H, W, S, seed):
 
 
 @pytest.mark.parametrize("B,H,W,S,scale", [(2, 192, 640, 2, 0), (2, 192, 640, 2, 2), (1, 192, 640, 3, 3),
-                                           (1, 100, 150, 2, 0)])
+                                           (1, 100, 150, 2, 0), (1, 320, 1024, 2, 1), (1, 192, 640, 4, 1),
+                                           (3, 64, 68, 1, 0)])
 def test_fused_vs_oracle_full_size(G, B, H, W, S, scale):
     """BASELINE-size tiles (192x640) and a ragged size, against the CPU oracle on seeded inputs."""
     from oracle import oracle as orc
@@ -202,3 +203,45 @@ def test_fused_vs_oracle_full_size(G, B, H, W, S, scale):
     gd, gP = orc.photometric_bwd(disp, colors[0], colors[1:], invK, P_ref, ref["idx"], 1.0 / n)
     G.assert_close(dt.grad, gd, "grad disp")
     G.assert_close(Pt.grad, gP, "grad P")
+
+
+def test_fused_without_automask_and_recompute_backward(G):
+    """use_automasking=False (reprojection channels only, processor.py:197-198) and the backward's re-warp path
+    (save_warp=False) against the oracle at 192x640."""
+    from oracle import oracle as orc
+    B, H, W, S = 1, 192, 640, 2
+    colors, K, invK, Ts, rng = _synth(B, H, W, S, seed=99)
+    disp = rng.rand(B, 1, H // 2, W // 2).astype(np.float32)
+    P_ref = np.stack([orc.compose_projection(K, T) for T in Ts])
+    ref = orc.photometric_fwd(disp, colors[0], colors[1:], invK, P_ref, None, automask=False, full=True)
+    n = B * H * W
+    gd, gP = orc.photometric_bwd(disp, colors[0], colors[1:], invK, P_ref, ref["idx"], 1.0 / n, automask=False)
+    srcs = [G.t(x) for x in colors[1:]]
+    for save_warp in (True, False):
+        dt = G.t(disp).requires_grad_(True)
+        Pt = G.t(P_ref).requires_grad_(True)
+        out = G.F.photometric_scale(dt, Pt, G.t(colors[0]), srcs, G.t(invK), automask=False, need_to_opt=True,
+                                    save_warp=save_warp)
+        G.assert_bitexact(out["to_opt"], ref["to_opt"], "to_opt")
+        assert (out["idx"].cpu().numpy() == ref["idx"]).all()
+        (out["sum"][0] / n).backward()
+        G.assert_close(dt.grad, gd, "grad disp (save_warp=%s)" % save_warp)
+        G.assert_close(Pt.grad, gP, "grad P (save_warp=%s)" % save_warp)
+
+
+def test_abi_reports_misuse_on_gpu(G):
+    """Error behaviour through the binding: wrong dtype / non-contiguous / misaligned pointers raise, nothing crashes."""
+    import ctypes as C
+    from mdx import _lib
+    x = torch.rand(1, 3, 32, 64, device=G.DEV)
+    with pytest.raises(_lib.MdxError):
+        _lib.ptr(x.double())
+    with pytest.raises(_lib.MdxError):
+        _lib.ptr(x[:, :, :, ::2])
+    d = _lib.make_desc(1, 32, 64, 32, 64, 1, False, 0.1, 100.0)
+    src = _lib.make_sources([x])
+    buf = torch.rand(1 * 3 * 32 * 64 + 1, device=G.DEV)
+    mis = buf[1:].view(1, 3, 32, 64)            # 4-byte aligned only
+    out = torch.empty(1, 1, 32, 64, device=G.DEV)
+    rc = _lib.lib().mdx_identity_loss(C.byref(d), C.c_void_p(mis.data_ptr()), C.byref(src), _lib.ptr(out), _lib.stream())
+    assert rc == -6   # MDX_ERR_MISALIGNED
