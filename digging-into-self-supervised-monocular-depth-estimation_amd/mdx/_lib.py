@@ -49,6 +49,18 @@ def lib():
     """Loads libmdx_hip.so; raises MdxError loudly if it is absent or incomplete."""
     global _lib
     if _lib is None:
+        if not os.path.exists(LIB_PATH) and not os.environ.get("MDX_LIB"):
+            # source-only checkout on a machine with the ROCm toolchain: compile the kernels now (this is the
+            # product path building itself, not a fallback -- without hipcc the error below stands)
+            try:
+                import importlib.util
+                spec = importlib.util.spec_from_file_location(
+                    "_mdx_build", os.path.join(os.path.dirname(LIB_PATH), "build.py"))
+                mod = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(mod)
+                mod.build()
+            except Exception as exc:  # noqa: BLE001
+                raise MdxError("libmdx_hip.so is missing and could not be built with hipcc: %s" % exc)
         if not os.path.exists(LIB_PATH):
             raise MdxError("libmdx_hip.so not found at %s -- build it with "
                            "`python __graft_entry__.py build` (hipcc --offload-arch=gfx950); "
