@@ -90,6 +90,7 @@ def time_kernels(device, B, H, W, S, reps=20):
             disp = torch.sigmoid(torch.nn.functional.interpolate(lo, size=(h, w), mode="bilinear",
                                                                  align_corners=False)).contiguous().to(device)
             warp = torch.empty(S, B, 3, H, W, device=device)
+            coef = torch.empty(B, 9, H, W, device=device)
             d = _lib.make_desc(B, H, W, h, w, S, True, 0.1, 100.0)
             nws = lib.mdx_photometric_workspace_bytes(C.byref(d))
             ws = torch.empty(nws // 8 + 1, dtype=torch.float64, device=device)
@@ -100,12 +101,12 @@ def time_kernels(device, B, H, W, S, reps=20):
                 _lib.check(lib.mdx_photometric_fwd(
                     C.byref(d), _lib.ptr(disp), _lib.ptr(tgt), C.byref(src), _lib.ptr(invK), _lib.ptr(P),
                     _lib.ptr(ident), _lib.ptr(noise), _lib.ptr(idx, torch.uint8), None, None, None, _lib.ptr(warp),
-                    None, _lib.ptr(ws, torch.float64), C.c_size_t(nws), _lib.stream()), "fwd")
+                    None, _lib.ptr(coef), _lib.ptr(ws, torch.float64), C.c_size_t(nws), _lib.stream()), "fwd")   # training form
 
             def bwd():
                 _lib.check(lib.mdx_photometric_bwd(
                     C.byref(d), _lib.ptr(disp), _lib.ptr(tgt), C.byref(src), _lib.ptr(invK), _lib.ptr(P),
-                    _lib.ptr(idx, torch.uint8), _lib.ptr(warp), C.c_float(1e-6), None, None, None,
+                    _lib.ptr(idx, torch.uint8), _lib.ptr(warp), _lib.ptr(coef), C.c_float(1e-6), None, None, None,
                     _lib.ptr(ws, torch.float64), C.c_size_t(nws), _lib.stream()), "bwd")   # fused kernel alone
             fwd()
             fn = fwd if name == "fwd" else bwd
@@ -292,7 +293,7 @@ def main():
             dom = max(k, key=lambda n: k[n]["ms"])
             for n in k:
                 k[n]["GBs"] = k[n]["bytes"] / (k[n]["ms"] * 1e-3) / 1e9
-            kname = {"fwd": "mdx::photometric_fwd_kernel<2, false>", "bwd": "mdx::photometric_bwd_kernel<2, true>"}
+            kname = {"fwd": "mdx::photometric_fwd_kernel<2, false, true>", "bwd": "mdx::photometric_bwd_coef_kernel<2>"}
             # HBM-side bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE are
             # collected in separate runs of tools/kbench.py; see profiles/r01_kernel_pmc.txt), null if absent
             traffic = {}

@@ -214,7 +214,8 @@ MDX_EXPORT int mdx_photometric_fwd(const mdx_desc *d, const float *disp, const f
                                    const mdx_sources *src, const float *invK, const float *P,
                                    const float *ident, const float *noise, uint8_t *idx,
                                    float *loss_sum, float *to_opt, float *depth, float *warp,
-                                   float *reproj, void *workspace, size_t workspace_bytes, void *stream)
+                                   float *reproj, float *coef, void *workspace, size_t workspace_bytes,
+                                   void *stream)
 {
     int rc = validate_desc(d);
     if (rc) return rc;
@@ -223,12 +224,13 @@ MDX_EXPORT int mdx_photometric_fwd(const mdx_desc *d, const float *disp, const f
     if ((rc = check_sources(d, src))) return rc;
     if (!workspace || workspace_bytes < ws_total(d)) return MDX_ERR_WORKSPACE;
     // 16-byte loads/stores on the image planes: torch allocations are 256-byte aligned
-    if (!aligned(workspace, 8) || !aligned(target, 16) || !aligned(disp, 16) || (warp && !aligned(warp, 16)))
+    if (!aligned(workspace, 8) || !aligned(target, 16) || !aligned(disp, 16) || (warp && !aligned(warp, 16)) ||
+        (coef && !aligned(coef, 16)))
         return MDX_ERR_MISALIGNED;
     FwdArgs a = {};
     a.d = *d; a.disp = disp; a.target = target; a.src = *src; a.invK = invK; a.P = P;
     a.ident = ident; a.noise = noise; a.idx = idx; a.to_opt = to_opt; a.depth = depth; a.warp = warp;
-    a.reproj = reproj; a.partials = (double *)workspace;
+    a.reproj = reproj; a.coef = coef; a.partials = (double *)workspace;
     rc = launch_photometric_fwd(a, false, (hipStream_t)stream);
     if (rc || !loss_sum) return rc;   // loss_sum == NULL: leave the per-tile partials in the workspace
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream,
@@ -238,9 +240,9 @@ MDX_EXPORT int mdx_photometric_fwd(const mdx_desc *d, const float *disp, const f
 
 MDX_EXPORT int mdx_photometric_bwd(const mdx_desc *d, const float *disp, const float *target,
                                    const mdx_sources *src, const float *invK, const float *P,
-                                   const uint8_t *idx, const float *warp, float g_const,
-                                   const float *g_dev, float *gdisp, float *gP, void *workspace,
-                                   size_t workspace_bytes, void *stream)
+                                   const uint8_t *idx, const float *warp, const float *coef,
+                                   float g_const, const float *g_dev, float *gdisp, float *gP,
+                                   void *workspace, size_t workspace_bytes, void *stream)
 {
     int rc = validate_desc(d);
     if (rc) return rc;
@@ -248,7 +250,8 @@ MDX_EXPORT int mdx_photometric_bwd(const mdx_desc *d, const float *disp, const f
     if ((gdisp == nullptr) != (gP == nullptr)) return MDX_ERR_NULL_POINTER;
     if ((rc = check_sources(d, src))) return rc;
     if (!workspace || workspace_bytes < ws_total(d)) return MDX_ERR_WORKSPACE;
-    if (!aligned(workspace, 8) || !aligned(target, 16) || (warp && !aligned(warp, 16))) return MDX_ERR_MISALIGNED;
+    if (!aligned(workspace, 8) || !aligned(target, 16) || (warp && !aligned(warp, 16)) || (coef && !aligned(coef, 16)))
+        return MDX_ERR_MISALIGNED;
     hipStream_t st = (hipStream_t)stream;
     // gdisp == gP == NULL: run the fused kernel only and leave its raw outputs (per-tile d(P) partials, the
     // full-resolution disparity gradient) in the workspace -- used to time that kernel in isolation
@@ -256,7 +259,8 @@ MDX_EXPORT int mdx_photometric_bwd(const mdx_desc *d, const float *disp, const f
     const bool same = !raw && (d->h == d->H && d->w == d->W);
     BwdArgs a = {};
     a.d = *d; a.disp = disp; a.target = target; a.src = *src; a.invK = invK; a.P = P; a.idx = idx;
-    a.warp = warp; a.g_const = g_const; a.g_dev = g_dev;
+    if (coef && !warp) return MDX_ERR_NULL_POINTER;   // the coefficient path also reads the warped colours
+    a.warp = warp; a.coef = coef; a.g_const = g_const; a.g_dev = g_dev;
     a.partP = (float *)((char *)workspace + ws_off_partP(d));
     a.gup = same ? gdisp : (float *)((char *)workspace + ws_off_gup(d));
     if ((rc = launch_photometric_bwd(a, st)) || raw) return rc;

@@ -15,6 +15,7 @@ struct FwdArgs {
     const float *invK, *P, *ident, *noise;
     uint8_t *idx;
     float *to_opt, *depth, *warp, *reproj;
+    float *coef;         // optional [B,9,H,W]: (alpha,beta,gamma) x channel of the selected frame (training)
     double *partials;
 };
 
@@ -25,6 +26,7 @@ struct BwdArgs {
     const float *invK, *P;
     const uint8_t *idx;
     const float *warp;   // optional [S,B,3,H,W]: the forward's warped colours (skips the re-warp)
+    const float *coef;   // optional [B,9,H,W]: the forward's SSIM coefficient maps (needs warp too)
     float g_const;
     const float *g_dev;
     float *gup;          // [B,H,W] d loss / d upsampled disparity

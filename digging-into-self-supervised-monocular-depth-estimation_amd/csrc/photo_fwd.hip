@@ -66,11 +66,11 @@ MDX_DEV float upsample_staged(const float *s_d, const DispRegion &r, const mdx_d
     return up_combine(r0[tx.i0], r0[tx.i1], r1[tx.i0], r1[tx.i1], ty, tx, (d.flags & MDX_FLAG_UPSAMPLE_PREMUL) != 0);
 }
 
-template <int S, bool IDENT>
-#ifndef MDX_FWD_WAVES
-#define MDX_FWD_WAVES 5
-#endif
-__global__ __launch_bounds__(NT, MDX_FWD_WAVES) void photometric_fwd_kernel(FwdArgs a)
+// COEF: training variant -- besides the loss it emits, for every pixel whose arg-min is a reprojection channel,
+// the three SSIM coefficient maps (alpha, beta, gamma per colour channel) of that frame: the window statistics
+// are in registers here anyway, so the backward kernel (photo_bwd.hip, coefficient path) never rebuilds them.
+template <int S, bool IDENT, bool COEF>
+MDX_DEV void photometric_fwd_body(const FwdArgs &a)
 {
     __shared__ float s_t[3][FY][FX];
     __shared__ float s_x[S][3][FY][FX];
@@ -203,6 +203,7 @@ __global__ __launch_bounds__(NT, MDX_FWD_WAVES) void photometric_fwd_kernel(FwdA
             ts[c] = target_stats(y9[c]);
         }
         float rl[S];
+        SsimTerms st[COEF ? S : 1][3];
 #pragma unroll
         for (int f = 0; f < S; ++f) {
             float ss[3], ad[3];
@@ -211,7 +212,9 @@ __global__ __launch_bounds__(NT, MDX_FWD_WAVES) void photometric_fwd_kernel(FwdA
                 float x9[9];
 #pragma unroll
                 for (int k = 0; k < 9; ++k) x9[k] = s_x[f][c][r + k / 3][tx + k % 3];
-                ss[c] = clamp01(ssim_raw(pred_stats(x9, y9[c]), ts[c]));
+                const SsimTerms stc = pred_stats(x9, y9[c]);
+                if (COEF) st[COEF ? f : 0][c] = stc;
+                ss[c] = clamp01(ssim_raw(stc, ts[c]));
                 ad[c] = fabsf(y9[c][4] - x9[4]);
             }
             rl[f] = reprojection_combine(ss, ad);
@@ -242,6 +245,23 @@ __global__ __launch_bounds__(NT, MDX_FWD_WAVES) void photometric_fwd_kernel(FwdA
             if (a.to_opt) a.to_opt[(size_t)b * HW + p] = best;
             acc += (double)best;
         }
+        if (COEF) {
+            // coefficient maps of the selected frame (zero where an identity channel won: the auto-mask)
+            const int fsel = automask ? bi - S : bi;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                SsimTerms sel = st[0][c];
+#pragma unroll
+                for (int f = 1; f < S; ++f)
+                    if (fsel == f) sel = st[COEF ? f : 0][c];
+                SsimGrad sg = ssim_grad(sel, ts[c], 0.85f / 3.0f);
+                if (fsel < 0) { sg.alpha = 0.f; sg.beta = 0.f; sg.gamma = 0.f; }
+                if (valid) {
+                    float *o = a.coef + ((size_t)b * 9 + c * 3) * HW + p;
+                    o[0] = sg.alpha; o[HW] = sg.beta; o[2 * HW] = sg.gamma;
+                }
+            }
+        }
     }
     if (IDENT) return;
     acc = wave_sum(acc);
@@ -255,15 +275,41 @@ __global__ __launch_bounds__(NT, MDX_FWD_WAVES) void photometric_fwd_kernel(FwdA
     }
 }
 
-template <bool IDENT>
+template <int S, bool IDENT>
+__global__ __launch_bounds__(NT, 5) void photometric_fwd_kernel(FwdArgs a)
+{
+    photometric_fwd_body<S, IDENT, false>(a);
+}
+
+// training form: exactly four waves per SIMD (128 VGPRs) -- the window statistics of every frame stay live until
+// the arg-min is known
+template <int S>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void photometric_fwd_coef_kernel(FwdArgs a)
+{
+    photometric_fwd_body<S, false, true>(a);
+}
+
+template <bool IDENT, bool COEF>
 static int launch_fwd_t(const FwdArgs &a, hipStream_t st)
 {
     const dim3 grid = tile_grid(&a.d);
     switch (a.d.S) {
-    case 1: hipLaunchKernelGGL((photometric_fwd_kernel<1, IDENT>), grid, dim3(NT), 0, st, a); break;
-    case 2: hipLaunchKernelGGL((photometric_fwd_kernel<2, IDENT>), grid, dim3(NT), 0, st, a); break;
-    case 3: hipLaunchKernelGGL((photometric_fwd_kernel<3, IDENT>), grid, dim3(NT), 0, st, a); break;
-    case 4: hipLaunchKernelGGL((photometric_fwd_kernel<4, IDENT>), grid, dim3(NT), 0, st, a); break;
+    case 1:
+        if constexpr (COEF) hipLaunchKernelGGL((photometric_fwd_coef_kernel<1>), grid, dim3(NT), 0, st, a);
+        else hipLaunchKernelGGL((photometric_fwd_kernel<1, IDENT>), grid, dim3(NT), 0, st, a);
+        break;
+    case 2:
+        if constexpr (COEF) hipLaunchKernelGGL((photometric_fwd_coef_kernel<2>), grid, dim3(NT), 0, st, a);
+        else hipLaunchKernelGGL((photometric_fwd_kernel<2, IDENT>), grid, dim3(NT), 0, st, a);
+        break;
+    case 3:
+        if constexpr (COEF) hipLaunchKernelGGL((photometric_fwd_coef_kernel<3>), grid, dim3(NT), 0, st, a);
+        else hipLaunchKernelGGL((photometric_fwd_kernel<3, IDENT>), grid, dim3(NT), 0, st, a);
+        break;
+    case 4:
+        if constexpr (COEF) hipLaunchKernelGGL((photometric_fwd_coef_kernel<4>), grid, dim3(NT), 0, st, a);
+        else hipLaunchKernelGGL((photometric_fwd_kernel<4, IDENT>), grid, dim3(NT), 0, st, a);
+        break;
     default: return MDX_ERR_BAD_SHAPE;
     }
     return check_launch();
@@ -271,7 +317,8 @@ static int launch_fwd_t(const FwdArgs &a, hipStream_t st)
 
 int launch_photometric_fwd(const FwdArgs &a, bool ident, hipStream_t st)
 {
-    return ident ? launch_fwd_t<true>(a, st) : launch_fwd_t<false>(a, st);
+    if (ident) return launch_fwd_t<true, false>(a, st);
+    return a.coef ? launch_fwd_t<false, true>(a, st) : launch_fwd_t<false, false>(a, st);
 }
 
 }  // namespace mdx

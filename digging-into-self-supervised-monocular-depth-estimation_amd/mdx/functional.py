@@ -93,16 +93,21 @@ class _PhotometricScale(torch.autograd.Function):
         warp = torch.empty(S, B, 3, H, W, device=dev, dtype=torch.float32) \
             if (cfg.get("need_warp") or keep_warp) else None
         reproj = torch.empty(B, S, H, W, device=dev, dtype=torch.float32) if cfg.get("need_reproj") else None
+        # ... and the SSIM coefficient maps of each pixel's arg-min frame (53 MB per scale at B=12): with them the
+        # backward kernel is the gather + geometry chain only
+        coef = torch.empty(B, 9, H, W, device=dev, dtype=torch.float32) \
+            if (keep_warp and cfg.get("save_coef", True)) else None
         nws = lib().mdx_photometric_workspace_bytes(C.byref(d))
         ws = _ws(nws, dev)
         check(lib().mdx_photometric_fwd(
             C.byref(d), ptr(disp), ptr(target), C.byref(src), ptr(invK), ptr(P),
             ptr(ident, optional=True) if automask else None, ptr(noise, optional=True) if automask else None,
             ptr(idx, torch.uint8), ptr(loss_sum), ptr(to_opt, optional=True), ptr(depth, optional=True),
-            ptr(warp, optional=True), ptr(reproj, optional=True), ptr(ws, torch.float64), C.c_size_t(nws),
-            stream()), "mdx_photometric_fwd")
+            ptr(warp, optional=True), ptr(reproj, optional=True), ptr(coef, optional=True), ptr(ws, torch.float64),
+            C.c_size_t(nws), stream()), "mdx_photometric_fwd")
         ctx.save_for_backward(disp, P, target, invK, idx, *sources)
         ctx.warp = warp if keep_warp else None
+        ctx.coef = coef
         ctx.cfg = dict(cfg)
         ctx.mark_non_differentiable(*[t for t in (idx, to_opt, depth, warp, reproj) if t is not None])
         return (loss_sum, idx, to_opt, depth, warp, reproj)
@@ -124,14 +129,15 @@ class _PhotometricScale(torch.autograd.Function):
         ws = _ws(nws, dev)
         check(lib().mdx_photometric_bwd(
             C.byref(d), ptr(disp), ptr(target), C.byref(src), ptr(invK), ptr(P), ptr(idx, torch.uint8),
-            ptr(ctx.warp, optional=True), C.c_float(1.0), ptr(g_dev), ptr(gdisp), ptr(gP), ptr(ws, torch.float64),
+            ptr(ctx.warp, optional=True), ptr(ctx.coef, optional=True), C.c_float(1.0), ptr(g_dev), ptr(gdisp), ptr(gP),
+            ptr(ws, torch.float64),
             C.c_size_t(nws), stream()), "mdx_photometric_bwd")
         return (gdisp, gP, None, None, None, None, None) + (None,) * S
 
 
 def photometric_scale(disp, P, target, sources, invK, ident=None, noise=None, automask=True,
                       min_depth=0.1, max_depth=100.0, need_to_opt=False, need_depth=False,
-                      need_warp=False, need_reproj=False, save_warp=True):
+                      need_warp=False, need_reproj=False, save_warp=True, save_coef=True):
     """Fused warp + SSIM/L1 + min for one scale.
 
     disp [B,1,h,w] (grad), P [S,B,3,4] (grad), target [B,3,H,W], sources: list of S [B,3,H,W],
@@ -141,7 +147,7 @@ def photometric_scale(disp, P, target, sources, invK, ident=None, noise=None, au
     """
     cfg = dict(automask=bool(automask), min_depth=float(min_depth), max_depth=float(max_depth),
                need_to_opt=need_to_opt, need_depth=need_depth, need_warp=need_warp, need_reproj=need_reproj,
-               save_warp=save_warp)
+               save_warp=save_warp, save_coef=save_coef)
     out = _PhotometricScale.apply(disp, P, target, invK, ident, noise, cfg, *sources)
     return dict(zip(("sum", "idx", "to_opt", "depth", "warp", "reproj"), out))
 

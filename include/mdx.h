@@ -92,22 +92,27 @@ size_t mdx_photometric_workspace_bytes(const mdx_desc *d);
  * Outputs: idx [B,H,W] uint8 (arg-min channel, torch.min's first-minimum rule);
  *          loss_sum [1] float = sum over B,H,W of to_optimise (divide by B*H*W for .mean()); NULL skips
  *          the finishing pass and leaves one double per tile at the start of the workspace;
- * optional (NULL to skip): to_opt [B,H,W]; depth [B,1,H,W]; warp [S,B,3,H,W]; reproj [B,S,H,W]. */
+ * optional (NULL to skip): to_opt [B,H,W]; depth [B,1,H,W]; warp [S,B,3,H,W]; reproj [B,S,H,W];
+ *          coef [B,9,H,W] = the SSIM coefficient maps (alpha,beta,gamma per colour channel) of each pixel's
+ *          arg-min frame, zero where an identity channel won -- hand warp and coef to mdx_photometric_bwd. */
 int mdx_photometric_fwd(const mdx_desc *d, const float *disp, const float *target,
                         const mdx_sources *src, const float *invK, const float *P,
                         const float *ident, const float *noise, uint8_t *idx, float *loss_sum,
-                        float *to_opt, float *depth, float *warp, float *reproj, void *workspace,
-                        size_t workspace_bytes, void *stream);
+                        float *to_opt, float *depth, float *warp, float *reproj, float *coef,
+                        void *workspace, size_t workspace_bytes, void *stream);
 
 /* Backward of the above for d(loss)/d(to_optimise[b,y,x]) = g_const * (*g_dev) on every pixel
  * (g_dev may be NULL = 1).  Needs only the inputs and idx; `warp` (optional, [S,B,3,H,W]) is the forward's
- * warped-colour output -- when given the kernel reads it instead of re-warping the 2-pixel halo.
+ * warped-colour output -- when given the kernel reads it instead of re-warping the 2-pixel halo; `coef`
+ * (optional, [B,9,H,W], needs warp) is the forward's coefficient output -- with it the backward skips the
+ * window statistics altogether.
  * Outputs: gdisp [B,1,h,w]; gP [S,B,3,4] (d loss / d P; chain to T with K^T outside).  Passing NULL for BOTH
  * runs the fused kernel alone and leaves its raw per-tile outputs in the workspace (timing aid). */
 int mdx_photometric_bwd(const mdx_desc *d, const float *disp, const float *target,
                         const mdx_sources *src, const float *invK, const float *P,
-                        const uint8_t *idx, const float *warp, float g_const, const float *g_dev,
-                        float *gdisp, float *gP, void *workspace, size_t workspace_bytes, void *stream);
+                        const uint8_t *idx, const float *warp, const float *coef, float g_const,
+                        const float *g_dev, float *gdisp, float *gP, void *workspace, size_t workspace_bytes,
+                        void *stream);
 
 /* Edge-aware smoothness   replaces model_loss.py:77-88,112-115 (processor.py:208).
  * disp [B,1,h,w], color [B,3,h,w] -> loss [1]; gdisp (optional) = d loss / d disp for unit upstream.

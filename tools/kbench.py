@@ -28,7 +28,8 @@ def main():
     ap.add_argument("--W", type=int, default=640)
     ap.add_argument("--S", type=int, default=2)
     ap.add_argument("--what", type=str, default="fwd,bwd,ident,smooth")
-    ap.add_argument("--save_warp", type=int, default=1, help="forward stores the warp, backward re-reads it")
+    ap.add_argument("--save_warp", type=int, default=2,
+                    help="0: backward re-warps; 1: forward stores the warp; 2: warp + SSIM coefficient maps (training form)")
     a = ap.parse_args()
     dev = "cuda:0"
     lib = _lib.lib()
@@ -60,6 +61,7 @@ def main():
         disp = torch.sigmoid(torch.nn.functional.interpolate(lo, size=(h, w), mode="bilinear",
                                                              align_corners=False)).contiguous().to(dev)
         warp = torch.empty(S, B, 3, H, W, device=dev)
+        coef = torch.empty(B, 9, H, W, device=dev)
         color_s = torch.nn.functional.avg_pool2d(tgt, 2 ** s) if s else tgt
         d = _lib.make_desc(B, H, W, h, w, S, True, 0.1, 100.0)
         nws = lib.mdx_photometric_workspace_bytes(C.byref(d))
@@ -73,13 +75,14 @@ def main():
             _lib.check(lib.mdx_photometric_fwd(
                 C.byref(d), _lib.ptr(disp), _lib.ptr(tgt), C.byref(src), _lib.ptr(invK), _lib.ptr(P),
                 _lib.ptr(ident), _lib.ptr(noise), _lib.ptr(idx, torch.uint8), None, None, None,
-                _lib.ptr(warp) if a.save_warp else None, None,
+                _lib.ptr(warp) if a.save_warp else None, None, _lib.ptr(coef) if a.save_warp == 2 else None,
                 _lib.ptr(ws, torch.float64), C.c_size_t(nws), _lib.stream()), "fwd")
 
         def bwd():
             _lib.check(lib.mdx_photometric_bwd(
                 C.byref(d), _lib.ptr(disp), _lib.ptr(tgt), C.byref(src), _lib.ptr(invK), _lib.ptr(P),
-                _lib.ptr(idx, torch.uint8), _lib.ptr(warp) if a.save_warp else None, C.c_float(1e-6), None, _lib.ptr(gdisp), _lib.ptr(gP),
+                _lib.ptr(idx, torch.uint8), _lib.ptr(warp) if a.save_warp else None,
+                _lib.ptr(coef) if a.save_warp == 2 else None, C.c_float(1e-6), None, _lib.ptr(gdisp), _lib.ptr(gP),
                 _lib.ptr(ws, torch.float64), C.c_size_t(nws), _lib.stream()), "bwd")
 
         def ident_fn():
