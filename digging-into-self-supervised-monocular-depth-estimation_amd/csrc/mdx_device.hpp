@@ -187,8 +187,13 @@ MDX_DEV Corners load_corners(const float *__restrict__ img, int H, int W, const 
     const bool shifted = xl != t.x0;            // x0 == W-1: the east taps are out of range
     const bool ys = t.y0 + 1 < H;
     const int y1 = ys ? t.y0 + 1 : t.y0;
-    const float2_a4 top = *reinterpret_cast<const float2_a4 *>(img + (size_t)t.y0 * W + xl);
-    const float2_a4 bot = *reinterpret_cast<const float2_a4 *>(img + (size_t)y1 * W + xl);
+    // 32-bit unsigned element offsets from a wave-uniform plane pointer: the loads then use the
+    // scalar-base + 32-bit-VGPR-offset addressing form instead of a 64-bit address pair per load
+    // (the BYTE offset is formed in 32 bits: only then can the compiler keep it out of 64-bit arithmetic)
+    const unsigned o0 = (unsigned)(t.y0 * W + xl) * 4u, o1 = (unsigned)(y1 * W + xl) * 4u;
+    const char *base = reinterpret_cast<const char *>(img);
+    const float2_a4 top = *reinterpret_cast<const float2_a4 *>(base + o0);
+    const float2_a4 bot = *reinterpret_cast<const float2_a4 *>(base + o1);
     Corners c;
     c.nw = shifted ? top.y : top.x;
     c.ne = shifted ? 0.f : top.y;

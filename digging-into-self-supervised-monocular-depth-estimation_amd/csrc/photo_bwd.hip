@@ -275,13 +275,13 @@ __global__ __launch_bounds__(NT, MDX_BWD_WAVES) void photometric_bwd_kernel(BwdA
 // No window statistics, no channel passes, no re-warp: ~60 % fewer instructions than the kernel above.
 // ---------------------------------------------------------------------------------------------
 template <int S>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void photometric_bwd_coef_kernel(BwdArgs a)
+__global__ __launch_bounds__(NT, 3) void photometric_bwd_coef_kernel(BwdArgs a)
 {
-    constexpr int N_ABG = 9 * FY * FX, N_SEL = (FY * FX + 3) / 4;
-    constexpr int N_POOL = N_ABG + N_SEL, N_RED = S * 12 * NT;
-    __shared__ float pool[N_POOL > N_RED ? N_POOL : N_RED];
+    constexpr int N_ABG = 9 * FY * FX, N_SEL = (FY * FX + 3) / 4, N_RED = S * 12 * NT;
+    __shared__ float pool[N_ABG + N_SEL + N_RED];
     float(*s_abg)[FY][FX] = reinterpret_cast<float(*)[FY][FX]>(pool);                      // [3*channel + {a,b,g}]
     signed char(*s_sel)[FX] = reinterpret_cast<signed char(*)[FX]>(pool + N_ABG);          // frame or -1
+    float *s_red = pool + N_ABG + N_SEL;                                                    // d(P) partials
 
     const mdx_desc &d = a.d;
     const int H = d.H, W = d.W;
@@ -312,118 +312,102 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     const float g_scale = a.g_const * (a.g_dev ? a.g_dev[0] : 1.0f);
     const int tx = tid & 63;
     const int px = x0 + tx;
-    float accP[S][12];
+    float gdepth[ROWSB];
 #pragma unroll
-    for (int f = 0; f < S; ++f)
-#pragma unroll
-        for (int k = 0; k < 12; ++k) accP[f][k] = 0.f;
+    for (int q = 0; q < ROWSB; ++q) gdepth[q] = 0.f;
+    // frame by frame (rolled loop: one frame's taps, colours and sums live at a time -- 3 blocks/CU would
+    // otherwise spill), both rows of this thread inside
 #pragma unroll 1
-    for (int q = 0; q < ROWSB; ++q) {
-        const int r = ROWSB * (tid >> 6) + q;
-        const int py = y0 + r;
-        if (px >= W || py >= H) continue;
-        const size_t p = (size_t)py * W + px;
-        // reflection-pad fold: a pixel one step inside the border also receives the mirrored ring tap
-        const float wxs[3] = {px == 1 ? 2.f : 1.f, 1.f, px == W - 2 ? 2.f : 1.f};
-        const float wys[3] = {py == 1 ? 2.f : 1.f, 1.f, py == H - 2 ? 2.f : 1.f};
-        float mk[S][9];
-        bool any[S];
+    for (int f = 0; f < S; ++f) {
+        const float *Pf = a.P + ((size_t)f * d.B + b) * 12;
+        const float *src_b = a.src.img[f] + (size_t)b * 3 * HW;
+        const float *warp_b = a.warp + ((size_t)f * d.B + b) * 3 * HW;
+        float accP[12];
 #pragma unroll
-        for (int f = 0; f < S; ++f) any[f] = false;
+        for (int k = 0; k < 12; ++k) accP[k] = 0.f;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            const int sel = s_sel[r + k / 3][tx + k % 3];
-            const float wgt = wys[k / 3] * wxs[k % 3];
-#pragma unroll
-            for (int f = 0; f < S; ++f) {
-                mk[f][k] = sel == f ? wgt : 0.f;
-                any[f] = any[f] || sel == f;
-            }
-        }
-        const int csel = s_sel[r + 1][tx + 1];
-        // sampling geometry of this pixel for every frame
-        const PixelGeom g = pixel_geom(d, disp_b, invK_b, px, py);
-        Proj pr[S];
-        Tap tp[S];
-        float gu[S], gv[S];
-#pragma unroll
-        for (int f = 0; f < S; ++f) {
-            pr[f] = project_point(a.P + ((size_t)f * d.B + b) * 12, g.X0, g.X1, g.X2, 1.0f, nd, 1e-7f);
-            tp[f] = make_tap(pr[f].gx, pr[f].gy, H, W);
-            gu[f] = gv[f] = 0.f;
-        }
-        // one colour channel at a time (rolled loop: keeps the 27 coefficient reads of a channel from being
-        // hoisted on top of the other channels' and spilling)
-#pragma unroll 1
-        for (int c = 0; c < 3; ++c) {
-            const float yq = a.target[((size_t)b * 3 + c) * HW + p];
-            float xq[S];
-#pragma unroll
-            for (int f = 0; f < S; ++f) xq[f] = a.warp[(((size_t)f * d.B + b) * 3 + c) * HW + p];
-            float gA[S], gB[S], gC[S];
-#pragma unroll
-            for (int f = 0; f < S; ++f) gA[f] = gB[f] = gC[f] = 0.f;
-            const float *pa = &s_abg[0][0][0] + (size_t)(3 * c) * FY * FX + r * FX + tx;
+        for (int q = 0; q < ROWSB; ++q) {
+            const int r = ROWSB * (tid >> 6) + q;
+            const int py = y0 + r;
+            if (px >= W || py >= H) continue;
+            // window centres that selected this frame, with the reflection-pad fold (a pixel one step inside the
+            // border also receives the mirrored ring tap)
+            const float wxs[3] = {px == 1 ? 2.f : 1.f, 1.f, px == W - 2 ? 2.f : 1.f};
+            const float wys[3] = {py == 1 ? 2.f : 1.f, 1.f, py == H - 2 ? 2.f : 1.f};
+            float mk[9];
+            bool any = false;
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
-                const int o = (k / 3) * FX + k % 3;
-                const float al = pa[o], be = pa[FY * FX + o], ga = pa[2 * FY * FX + o];
+                const bool hit = s_sel[r + k / 3][tx + k % 3] == f;
+                mk[k] = hit ? wys[k / 3] * wxs[k % 3] : 0.f;
+                any = any || hit;
+            }
+            if (!any) continue;
+            const bool centre = s_sel[r + 1][tx + 1] == f;
+            const unsigned pb = (unsigned)(py * W + px) * 4u;   // byte offset inside a plane
+            float yq[3], xq[3];
 #pragma unroll
-                for (int f = 0; f < S; ++f) {
-                    gA[f] = __builtin_fmaf(mk[f][k], al, gA[f]);
-                    gB[f] = __builtin_fmaf(mk[f][k], be, gB[f]);
-                    gC[f] = __builtin_fmaf(mk[f][k], ga, gC[f]);
+            for (int c = 0; c < 3; ++c) {
+                yq[c] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.target + ((size_t)b * 3 + c) * HW) + pb);
+                xq[c] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(warp_b + c * HW) + pb);
+            }
+            const PixelGeom g = pixel_geom(d, disp_b, invK_b, px, py);
+            const Proj pr = project_point(Pf, g.X0, g.X1, g.X2, 1.0f, nd, 1e-7f);
+            const Tap t = make_tap(pr.gx, pr.gy, H, W);
+            Corners cn[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) cn[c] = load_corners(src_b + c * HW, H, W, t);
+            const float dy1 = (float)(t.y0 + 1) - t.iy, dy0 = t.iy - (float)t.y0;
+            const float dx1 = (float)(t.x0 + 1) - t.ix, dx0 = t.ix - (float)t.x0;
+            float gu = 0.f, gv = 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float gA = 0.f, gB = 0.f, gC = 0.f;
+                const float *pa = &s_abg[0][0][0] + (3 * c) * FY * FX + r * FX + tx;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    const int o = (k / 3) * FX + k % 3;
+                    gA = __builtin_fmaf(mk[k], pa[o], gA);
+                    gB = __builtin_fmaf(mk[k], pa[FY * FX + o], gB);
+                    gC = __builtin_fmaf(mk[k], pa[2 * FY * FX + o], gC);
                 }
+                float gx = (gA + 2.0f * xq[c] * gB + yq[c] * gC) * (1.0f / 9.0f);
+                if (centre) gx -= 0.05f * ((yq[c] > xq[c]) ? 1.f : ((yq[c] < xq[c]) ? -1.f : 0.f));   // 0.15*mean_c|y-x|
+                gu += gx * ((cn[c].ne - cn[c].nw) * dy1 + (cn[c].se - cn[c].sw) * dy0);
+                gv += gx * ((cn[c].sw - cn[c].nw) * dx1 + (cn[c].se - cn[c].ne) * dx0);
             }
-#pragma unroll
-            for (int f = 0; f < S; ++f) {
-                if (!any[f]) continue;
-                float gx = (gA[f] + 2.0f * xq[f] * gB[f] + yq * gC[f]) * (1.0f / 9.0f);
-                if (csel == f) gx -= 0.05f * ((yq > xq[f]) ? 1.f : ((yq < xq[f]) ? -1.f : 0.f));   // 0.15*mean_c|y-x|
-                const Tap &t = tp[f];
-                const Corners cn = load_corners(a.src.img[f] + ((size_t)b * 3 + c) * HW, H, W, t);
-                const float dy1 = (float)(t.y0 + 1) - t.iy, dy0 = t.iy - (float)t.y0;
-                const float dx1 = (float)(t.x0 + 1) - t.ix, dx0 = t.ix - (float)t.x0;
-                gu[f] += gx * ((cn.ne - cn.nw) * dy1 + (cn.se - cn.sw) * dy0);
-                gv[f] += gx * ((cn.sw - cn.nw) * dx1 + (cn.se - cn.ne) * dx0);
-            }
-        }
-        float gdepth = 0.f;
-#pragma unroll
-        for (int f = 0; f < S; ++f) {
-            if (!any[f]) continue;
-            const float *Pf = a.P + ((size_t)f * d.B + b) * 12;
             // grid normalisation (2/(W-1)) and grid_sample's un-normalisation ((W-1)/2) cancel
-            const float u_ = tp[f].inx ? gu[f] : 0.f;
-            const float v_ = tp[f].iny ? gv[f] : 0.f;
-            const float iz = 1.0f / pr[f].z;
-            const float gq0 = u_ * iz, gq1 = v_ * iz, gq2 = -(u_ * pr[f].u + v_ * pr[f].v) * iz;
+            gu = t.inx ? gu : 0.f;
+            gv = t.iny ? gv : 0.f;
+            const float iz = 1.0f / pr.z;
+            const float gq0 = gu * iz, gq1 = gv * iz, gq2 = -(gu * pr.u + gv * pr.v) * iz;
             const float X[4] = {g.X0, g.X1, g.X2, 1.0f};
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const float gX = gq0 * Pf[j] + gq1 * Pf[4 + j] + gq2 * Pf[8 + j];
-                gdepth += gX * g.r[j];
+                // depth = 1/(a + b*disp)  ->  d depth / d disp = -b * depth^2 (applied here, per frame)
+                gdepth[q] += gX * g.r[j] * (-d.disp_b * g.depth * g.depth);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                accP[f][j] += gq0 * X[j];
-                accP[f][4 + j] += gq1 * X[j];
-                accP[f][8 + j] += gq2 * X[j];
+                accP[j] += gq0 * X[j];
+                accP[4 + j] += gq1 * X[j];
+                accP[8 + j] += gq2 * X[j];
             }
         }
-        // depth = 1/(a + b*disp)  ->  d depth / d disp = -b * depth^2
-        a.gup[(size_t)b * HW + p] = gdepth * (-d.disp_b * g.depth * g.depth) * g_scale;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) s_red[(f * 12 + k) * NT + tid] = accP[k];
+    }
+#pragma unroll
+    for (int q = 0; q < ROWSB; ++q) {
+        const int py = y0 + ROWSB * (tid >> 6) + q;
+        if (px < W && py < H) a.gup[(size_t)b * HW + (size_t)py * W + px] = gdepth[q] * g_scale;
     }
 
     // ---- d(P): block reduction through LDS ----
     __syncthreads();
-#pragma unroll
-    for (int f = 0; f < S; ++f)
-#pragma unroll
-        for (int k = 0; k < 12; ++k) pool[(f * 12 + k) * NT + tid] = accP[f][k];
-    __syncthreads();
     for (int v = tid >> 6; v < S * 12; v += NT / 64) {
-        const float *pp = pool + v * NT + (tid & 63);
+        const float *pp = s_red + v * NT + (tid & 63);
         float t = (pp[0] + pp[64]) + (pp[128] + pp[192]);
         t = wave_sum(t);
         if ((tid & 63) == 0) a.partP[(size_t)tile.linear * (S * 12) + v] = t;
