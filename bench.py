@@ -293,7 +293,7 @@ def main():
             dom = max(k, key=lambda n: k[n]["ms"])
             for n in k:
                 k[n]["GBs"] = k[n]["bytes"] / (k[n]["ms"] * 1e-3) / 1e9
-            kname = {"fwd": "mdx::photometric_fwd_kernel<2, false, true>", "bwd": "mdx::photometric_bwd_coef_kernel<2>"}
+            kname = {"fwd": "mdx::photometric_fwd_coef_kernel<2>", "bwd": "mdx::photometric_bwd_coef_kernel<2>"}
             # HBM-side bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE are
             # collected in separate runs of tools/kbench.py; see profiles/r01_kernel_pmc.txt), null if absent
             traffic = {}
