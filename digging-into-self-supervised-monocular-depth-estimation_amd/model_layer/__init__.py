@@ -1,12 +1,9 @@
-"""Drop-in for the reference's model_layer package (same export list: model_layer/__init__.py:1-11)."""
+"""Drop-in for the reference's `model_layer` package: same public names as reference model_layer/__init__.py:1-11
+(four networks, six geometry / sampling ops)."""
 from .depth_encoder import ResnetEncoder
 from .depth_decoder import DepthDecoder
-from .pose_decoder import PoseCNN
-from .pose_decoder import PoseDecoder
+from .pose_decoder import PoseCNN, PoseDecoder
+from .warp import (Depth2PointCloud, PointCloud2Pixel, disparity2depth, grid_sample, interpolate, param2matrix)
 
-from .warp import interpolate
-from .warp import grid_sample
-from .warp import disparity2depth
-from .warp import param2matrix
-from .warp import Depth2PointCloud
-from .warp import PointCloud2Pixel
+__all__ = ["ResnetEncoder", "DepthDecoder", "PoseCNN", "PoseDecoder", "interpolate", "grid_sample",
+           "disparity2depth", "param2matrix", "Depth2PointCloud", "PointCloud2Pixel"]

@@ -1,78 +1,73 @@
-"""U-Net disparity decoder (reference: model_layer/depth_decoder.py:13-112).  State-dict keys
-`decoder.N.conv.conv.weight` in the reference's ModuleList order.  Convs run on MIOpen."""
-from collections import OrderedDict
+"""U-Net disparity decoder (behaviour of reference model_layer/depth_decoder.py:13-112).
 
+Five stages, deepest first; stage i = ConvBlock -> nearest x2 -> concat encoder skip (i > 0) -> ConvBlock, and a
+sigmoid disparity head on the stages listed in `scales`.  The parameter names are the reference's
+(`decoder.<n>.conv.conv.{weight,bias}`, n in the reference's ModuleList order: the ten stage blocks from stage 4
+down to stage 0, then one head per scale), so checkpoints are interchangeable.  Convolutions run on MIOpen.
+"""
 import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as TF
 
-
-def upsample(tensor):
-    return TF.interpolate(tensor, scale_factor=2, mode="nearest")
+STAGE_WIDTH = (16, 32, 64, 128, 256)
 
 
 class Conv3x3(nn.Module):
-    """reference: depth_decoder.py:36-50 (reflection or zero pad + 3x3 conv)."""
+    """3x3 convolution behind a one-pixel reflection (or zero) pad."""
 
     def __init__(self, in_channels, out_channels, use_refl=True):
         super().__init__()
-        self.pad = nn.ReflectionPad2d(1) if use_refl else nn.ZeroPad2d(1)
-        self.conv = nn.Conv2d(int(in_channels), int(out_channels), 3)
+        self.pad = (nn.ReflectionPad2d if use_refl else nn.ZeroPad2d)(1)
+        self.conv = nn.Conv2d(int(in_channels), int(out_channels), kernel_size=3)
 
-    def forward(self, inputs):
-        return self.conv(self.pad(inputs))
+    def forward(self, x):
+        return self.conv(self.pad(x))
 
 
 class ConvBlock(nn.Module):
-    """reference: depth_decoder.py:18-32 (Conv3x3 + ELU)."""
+    """Conv3x3 followed by ELU."""
 
     def __init__(self, in_channels, out_channels):
         super().__init__()
         self.conv = Conv3x3(in_channels, out_channels)
         self.elu = nn.ELU(inplace=True)
 
-    def forward(self, inputs):
-        return self.elu(self.conv(inputs))
+    def forward(self, x):
+        return self.elu(self.conv(x))
 
 
 class DepthDecoder(nn.Module):
-    """reference: depth_decoder.py:54-112.  features (5 maps) -> {("disp", s): sigmoid [B,1,H>>s,W>>s]}."""
-
     def __init__(self, num_ch_enc, scales=range(4), num_output_channels=1, use_skips=True):
         super().__init__()
         self.num_ch_enc = num_ch_enc
-        self.num_ch_dec = np.array([16, 32, 64, 128, 256])
-        self.num_output_channels = num_output_channels
-        self.use_skips = use_skips
-        self.upsample_mode = "nearest"
-        self.scales = scales
-        self.convs = OrderedDict()
-        for index in range(4, -1, -1):
-            num_ch_in = self.num_ch_enc[-1] if index == 4 else self.num_ch_dec[index + 1]
-            self.convs[("upconv", index, 0)] = ConvBlock(num_ch_in, self.num_ch_dec[index])
-            num_ch_in = self.num_ch_dec[index]
-            if self.use_skips and index > 0:
-                num_ch_in += self.num_ch_enc[index - 1]
-            self.convs[("upconv", index, 1)] = ConvBlock(num_ch_in, self.num_ch_dec[index])
-        for s in self.scales:
-            self.convs[("dispconv", s)] = Conv3x3(self.num_ch_dec[s], self.num_output_channels)
-        self.decoder = nn.ModuleList(list(self.convs.values()))
+        self.num_ch_dec = np.array(STAGE_WIDTH)
+        self.num_output_channels, self.use_skips, self.scales = num_output_channels, use_skips, scales
+        blocks, self._stage = [], {}
+        for i in (4, 3, 2, 1, 0):
+            wide = int(self.num_ch_dec[i])
+            fan_in = int(num_ch_enc[-1]) if i == 4 else int(self.num_ch_dec[i + 1])
+            skip = int(num_ch_enc[i - 1]) if (use_skips and i > 0) else 0
+            self._stage[i] = (len(blocks), len(blocks) + 1)
+            blocks += [ConvBlock(fan_in, wide), ConvBlock(wide + skip, wide)]
+        self._head = {}
+        for s in scales:
+            self._head[s] = len(blocks)
+            blocks.append(Conv3x3(int(self.num_ch_dec[s]), num_output_channels))
+        self.decoder = nn.ModuleList(blocks)
         self.sigmoid = nn.Sigmoid()
 
     def forward(self, input_features):
         self.outputs = {}
-        feature = input_features[-1]
-        for index in range(4, -1, -1):
-            feature = self.convs[("upconv", index, 0)](feature)
-            feature = [upsample(feature)]
-            if self.use_skips and index > 0:
-                feature += [input_features[index - 1]]
-            feature = torch.cat(feature, 1)
-            feature = self.convs[("upconv", index, 1)](feature)
-            if index in self.scales:
-                # the disparity head and sigmoid stay float32 even under bf16 autocast: the photometric
-                # kernels consume float32 disparity
-                with torch.autocast(device_type=feature.device.type, enabled=False):
-                    self.outputs[("disp", index)] = self.sigmoid(self.convs[("dispconv", index)](feature.float()))
+        x = input_features[-1]
+        for i in (4, 3, 2, 1, 0):
+            first, second = self._stage[i]
+            x = TF.interpolate(self.decoder[first](x), scale_factor=2, mode="nearest")
+            if self.use_skips and i > 0:
+                x = torch.cat((x, input_features[i - 1]), 1)
+            x = self.decoder[second](x)
+            if i in self._head:
+                # head + sigmoid stay float32 under bf16 autocast: the photometric kernels consume float32
+                with torch.autocast(device_type=x.device.type, enabled=False):
+                    self.outputs[("disp", i)] = self.sigmoid(self.decoder[self._head[i]](x.float()))
         return self.outputs

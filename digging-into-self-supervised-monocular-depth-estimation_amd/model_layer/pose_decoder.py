@@ -1,59 +1,51 @@
-"""Pose heads (reference: model_layer/pose_decoder.py:13-98).  State-dict keys `net.N.{weight,bias}`."""
-from collections import OrderedDict
-
+"""Pose heads (behaviour of reference model_layer/pose_decoder.py:13-98); parameter names `net.<n>.{weight,bias}`."""
 import torch
 import torch.nn as nn
 
 
 class PoseDecoder(nn.Module):
-    """reference: pose_decoder.py:13-58 -> (axisangle, translation), each [B, n_frames, 1, 3]."""
+    """Encoder features -> (axisangle, translation), each [B, frames, 1, 3], scaled by 0.01.
+    1x1 squeeze to 256 -> two 3x3 (ReLU) -> 1x1 to 6*frames -> spatial mean."""
 
     def __init__(self, num_ch_enc, num_input_features, num_frames_to_predict_for=None, stride=1):
         super().__init__()
-        self.num_ch_enc = num_ch_enc
-        self.num_input_features = num_input_features
-        if num_frames_to_predict_for is None:
-            num_frames_to_predict_for = num_input_features - 1
-        self.num_frames_to_predict_for = num_frames_to_predict_for
-        self.convs = OrderedDict()
-        self.convs[("squeeze")] = nn.Conv2d(int(self.num_ch_enc[-1]), 256, 1)
-        self.convs[("pose", 0)] = nn.Conv2d(num_input_features * 256, 256, 3, stride, 1)
-        self.convs[("pose", 1)] = nn.Conv2d(256, 256, 3, stride, 1)
-        self.convs[("pose", 2)] = nn.Conv2d(256, 6 * num_frames_to_predict_for, 1)
+        self.num_ch_enc, self.num_input_features = num_ch_enc, num_input_features
+        self.num_frames_to_predict_for = num_frames_to_predict_for or (num_input_features - 1)
+        self.net = nn.ModuleList([
+            nn.Conv2d(int(num_ch_enc[-1]), 256, 1),
+            nn.Conv2d(num_input_features * 256, 256, 3, stride, 1),
+            nn.Conv2d(256, 256, 3, stride, 1),
+            nn.Conv2d(256, 6 * self.num_frames_to_predict_for, 1),
+        ])
         self.relu = nn.ReLU()
-        self.net = nn.ModuleList(list(self.convs.values()))
 
     def forward(self, input_features):
-        last_features = [f[-1] for f in input_features]
-        cat_features = torch.cat([self.relu(self.convs["squeeze"](f)) for f in last_features], 1)
-        out = cat_features
-        for i in range(3):
-            out = self.convs[("pose", i)](out)
-            if i != 2:
-                out = self.relu(out)
-        out = out.float().mean(3).mean(2)
-        out = 0.01 * out.view(-1, self.num_frames_to_predict_for, 1, 6)
-        return out[..., :3], out[..., 3:]
+        squeezed = [self.relu(self.net[0](feats[-1])) for feats in input_features]
+        x = torch.cat(squeezed, 1)
+        x = self.relu(self.net[1](x))
+        x = self.relu(self.net[2](x))
+        x = self.net[3](x).float().mean(dim=(2, 3))
+        x = 0.01 * x.view(-1, self.num_frames_to_predict_for, 1, 6)
+        return x[..., :3], x[..., 3:]
 
 
 class PoseCNN(nn.Module):
-    """reference: pose_decoder.py:62-98 (the first conv is not followed by a ReLU there either)."""
+    """Seven strided convolutions on the stacked frames -> 1x1 pose head.  As in the reference, the first
+    convolution is not followed by a ReLU (pose_decoder.py:86-89)."""
 
     def __init__(self, num_input_frames):
         super().__init__()
         self.num_input_frames = num_input_frames
-        chans = [(3 * num_input_frames, 16, 7, 3), (16, 32, 5, 2), (32, 64, 3, 1), (64, 128, 3, 1),
-                 (128, 256, 3, 1), (256, 256, 3, 1), (256, 256, 3, 1)]
-        self.convs = {i: nn.Conv2d(ci, co, k, 2, p) for i, (ci, co, k, p) in enumerate(chans)}
+        spec = [(3 * num_input_frames, 16, 7), (16, 32, 5), (32, 64, 3), (64, 128, 3), (128, 256, 3), (256, 256, 3),
+                (256, 256, 3)]
+        self.net = nn.ModuleList([nn.Conv2d(ci, co, k, 2, k // 2) for ci, co, k in spec])
         self.pose_conv = nn.Conv2d(256, 6 * (num_input_frames - 1), 1)
-        self.num_convs = len(self.convs)
         self.relu = nn.ReLU(True)
-        self.net = nn.ModuleList(list(self.convs.values()))
 
     def forward(self, input_images):
-        output = self.convs[0](input_images)
-        for index in range(self.num_convs - 1):
-            output = self.relu(self.convs[index + 1](output))
-        output = self.pose_conv(output).float().mean(3).mean(2)
-        output = 0.01 * output.view(-1, self.num_input_frames - 1, 1, 6)
-        return output[..., :3], output[..., 3:]
+        x = self.net[0](input_images)
+        for conv in list(self.net)[1:]:
+            x = self.relu(conv(x))
+        x = self.pose_conv(x).float().mean(dim=(2, 3))
+        x = 0.01 * x.view(-1, self.num_input_frames - 1, 1, 6)
+        return x[..., :3], x[..., 3:]

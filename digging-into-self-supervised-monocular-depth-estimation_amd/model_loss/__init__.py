@@ -1,4 +1,6 @@
-"""Drop-in for the reference's model_loss package (export list: model_loss/__init__.py:1-3)."""
-from .model_loss import ReprojectionLoss
-from .model_loss import SmoothLoss
-from .model_metric import *  # noqa: F401,F403
+"""Drop-in for the reference's `model_loss` package (reference model_loss/__init__.py:1-3): the two loss modules
+and the depth metrics."""
+from .model_loss import ReprojectionLoss, SmoothLoss
+from .model_metric import compute_depth_error, compute_depth_metric
+
+__all__ = ["ReprojectionLoss", "SmoothLoss", "compute_depth_error", "compute_depth_metric"]
