@@ -12,6 +12,18 @@
 
 namespace mdx {
 
+// Element `i` of an array whose base pointer is wave-uniform (a plane of one image): the byte offset is
+// formed in 32 bits, so the access uses the scalar-base + 32-bit-VGPR-offset form (one VGPR, no 64-bit VALU
+// address arithmetic).  A plane is far below 4 GB.
+template <typename T> MDX_DEV const T &at32(const T *base, unsigned i)
+{
+    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + i * (unsigned)sizeof(T));
+}
+template <typename T> MDX_DEV T &at32(T *base, unsigned i)
+{
+    return *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + i * (unsigned)sizeof(T));
+}
+
 // ---------------------------------------------------------------------------------------------
 // A1  bilinear upsample, align_corners=False  (warp.py:18-20 via processor.py:142)
 // ---------------------------------------------------------------------------------------------

@@ -105,7 +105,7 @@ MDX_DEV void load_plane_tile(float (*dst)[TX + 2 * HALO], const float *__restric
             const int gy = y0 + ly - HALO;
             if (gy < -1 || gy > H) continue;
             const int py = reflect(gy, H);
-            const float4 v = *reinterpret_cast<const float4 *>(plane + (size_t)py * W + x0 + 4 * j);
+            const float4 v = *reinterpret_cast<const float4 *>(&at32(plane, (unsigned)(py * W + x0 + 4 * j)));
             float *o = &dst[ly][HALO + 4 * j];
             o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
         }
@@ -114,14 +114,14 @@ MDX_DEV void load_plane_tile(float (*dst)[TX + 2 * HALO], const float *__restric
             const int lx = e < HALO ? e : TX + e;
             const int gx = x0 + lx - HALO, gy = y0 + ly - HALO;
             if (gx < -1 || gx > W || gy < -1 || gy > H) continue;
-            dst[ly][lx] = plane[(size_t)reflect(gy, H) * W + reflect(gx, W)];
+            dst[ly][lx] = at32(plane, (unsigned)(reflect(gy, H) * W + reflect(gx, W)));
         }
     } else {
         for (int i = tid; i < NYT * NXT; i += NT) {
             const int ly = i / NXT, lx = i - ly * NXT;
             const int gx = x0 + lx - HALO, gy = y0 + ly - HALO;
             if (gx < -1 || gx > W || gy < -1 || gy > H) continue;
-            dst[ly][lx] = plane[(size_t)reflect(gy, H) * W + reflect(gx, W)];
+            dst[ly][lx] = at32(plane, (unsigned)(reflect(gy, H) * W + reflect(gx, W)));
         }
     }
 }

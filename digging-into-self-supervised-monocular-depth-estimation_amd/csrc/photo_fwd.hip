@@ -128,7 +128,7 @@ MDX_DEV void photometric_fwd_body(const FwdArgs &a)
             else if (reg.staged) up = upsample_staged(&s_d[0][0], reg, d, hp[k].py, hp[k].px);
             else up = upsample_at(disp_b, d.h, d.w, H, W, hp[k].py, hp[k].px, (d.flags & MDX_FLAG_UPSAMPLE_PREMUL) != 0);
             g[k] = geom_from_disp(d, up, invK_b, hp[k].px, hp[k].py);
-            if (a.depth && hp[k].interior) a.depth[(size_t)b * HW + (size_t)hp[k].py * W + hp[k].px] = g[k].depth;
+            if (a.depth && hp[k].interior) at32(a.depth + (size_t)b * HW, (unsigned)(hp[k].py * W + hp[k].px)) = g[k].depth;
         }
 #pragma unroll
         for (int f = 0; f < S; ++f) {
@@ -152,7 +152,7 @@ MDX_DEV void photometric_fwd_body(const FwdArgs &a)
                     const float v = sample(cn[k][c], t[k]);
                     if (hp[k].valid) s_x[f][c][hp[k].ly][hp[k].lx] = v;
                     if (a.warp && !wide && hp[k].interior)
-                        a.warp[(((size_t)f * d.B + b) * 3 + c) * HW + (size_t)hp[k].py * W + hp[k].px] = v;
+                        at32(a.warp + (((size_t)f * d.B + b) * 3 + c) * HW, (unsigned)(hp[k].py * W + hp[k].px)) = v;
                 }
         }
         __syncthreads();
@@ -164,7 +164,7 @@ MDX_DEV void photometric_fwd_body(const FwdArgs &a)
                 const float *sp = &s_x[0][0][0][0] + (size_t)fc * FY * FX + (r + 1) * FX + 1 + 4 * j;
                 const int f = fc / 3, c = fc - 3 * f;
                 float4 v = make_float4(sp[0], sp[1], sp[2], sp[3]);
-                *reinterpret_cast<float4 *>(a.warp + (((size_t)f * d.B + b) * 3 + c) * HW + (size_t)(y0 + r) * W + x0 + 4 * j) = v;
+                *reinterpret_cast<float4 *>(&at32(a.warp + (((size_t)f * d.B + b) * 3 + c) * HW, (unsigned)((y0 + r) * W + x0 + 4 * j))) = v;
             }
         }
     }
@@ -182,9 +182,9 @@ MDX_DEV void photometric_fwd_body(const FwdArgs &a)
             const bool valid = px < W && py < H;
 #pragma unroll
             for (int f = 0; f < S; ++f) {
-                const size_t o = ((size_t)b * S + f) * HW + (size_t)(valid ? py : 0) * W + (valid ? px : 0);
-                idv[q][f] = a.ident[o];
-                nzv[q][f] = a.noise[o];
+                const unsigned o = (unsigned)((valid ? py : 0) * W + (valid ? px : 0));
+                idv[q][f] = at32(a.ident + ((size_t)b * S + f) * HW, o);
+                nzv[q][f] = at32(a.noise + ((size_t)b * S + f) * HW, o);
             }
         }
     }
@@ -193,7 +193,7 @@ MDX_DEV void photometric_fwd_body(const FwdArgs &a)
         const int r = ROWS * (tid >> 6) + q;
         const int py = y0 + r;
         const bool valid = px < W && py < H;
-        const size_t p = (size_t)(valid ? py : 0) * W + (valid ? px : 0);
+        const unsigned p = (unsigned)((valid ? py : 0) * W + (valid ? px : 0));
         float y9[3][9];
         TargetStats ts[3];
 #pragma unroll
@@ -218,7 +218,7 @@ MDX_DEV void photometric_fwd_body(const FwdArgs &a)
                 ad[c] = fabsf(y9[c][4] - x9[4]);
             }
             rl[f] = reprojection_combine(ss, ad);
-            if (a.reproj && valid) a.reproj[((size_t)b * S + f) * HW + p] = rl[f];
+            if (a.reproj && valid) at32(a.reproj + ((size_t)b * S + f) * HW, p) = rl[f];
         }
         if (IDENT) continue;
         // concat [ident + 1e-5*noise, reproj] and torch.min's first-minimum rule (processor.py:194-204)
@@ -241,8 +241,8 @@ MDX_DEV void photometric_fwd_body(const FwdArgs &a)
                 if (rl[f] < best) { best = rl[f]; bi = f; }
         }
         if (valid) {
-            a.idx[(size_t)b * HW + p] = (uint8_t)bi;
-            if (a.to_opt) a.to_opt[(size_t)b * HW + p] = best;
+            at32(a.idx + (size_t)b * HW, p) = (uint8_t)bi;
+            if (a.to_opt) at32(a.to_opt + (size_t)b * HW, p) = best;
             acc += (double)best;
         }
         if (COEF) {
@@ -257,8 +257,8 @@ MDX_DEV void photometric_fwd_body(const FwdArgs &a)
                 SsimGrad sg = ssim_grad(sel, ts[c], 0.85f / 3.0f);
                 if (fsel < 0) { sg.alpha = 0.f; sg.beta = 0.f; sg.gamma = 0.f; }
                 if (valid) {
-                    float *o = a.coef + ((size_t)b * 9 + c * 3) * HW + p;
-                    o[0] = sg.alpha; o[HW] = sg.beta; o[2 * HW] = sg.gamma;
+                    float *o = a.coef + ((size_t)b * 9 + c * 3) * HW;
+                    at32(o, p) = sg.alpha; at32(o + HW, p) = sg.beta; at32(o + 2 * HW, p) = sg.gamma;
                 }
             }
         }
