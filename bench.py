@@ -213,6 +213,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=12)
     ap.add_argument("--amp", type=str, default="none", choices=["none", "bf16"])
+    ap.add_argument("--height", type=int, default=192)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--num-layers", type=int, default=18)
+    ap.add_argument("--frame-ids", type=str, default="0 -1 1", help='e.g. "0 -1 1 s" for mono+stereo (configs[4])')
     ap.add_argument("--channels-last", action="store_true", help="NHWC activations/weights for the conv nets")
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark (MIOpen find mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -237,7 +241,9 @@ def main():
     from model_tool import setting, compute
 
     torch.manual_seed(1234 + rank)
-    opt = make_opt(args.batch, amp=args.amp)
+    frame_ids = [t if t == "s" else int(t) for t in args.frame_ids.split()]
+    opt = make_opt(args.batch, height=args.height, width=args.width, frame_ids=frame_ids, num_layers=args.num_layers,
+                   amp=args.amp)
     opt.channels_last = args.channels_last
     torch.backends.cudnn.benchmark = args.miopen_find
     st = setting(opt, device)
@@ -282,18 +288,22 @@ def main():
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.amp == "none" else "bf16-nets/f32-loss", "data": "synthetic",
-            "config": {"workload": "configs[1]: kitti_eigen_zhou-shaped 192x640, batch %d/GPU, ResNet18 depth + "
-                                   "separate ResNet18 pose, frame_ids [0,-1,1], 4 scales, automask, Adam, fp32"
-                                   % args.batch,
+            "config": {"workload": "%skitti_eigen_zhou-shaped %dx%d, batch %d/GPU, ResNet%d depth + separate ResNet%d "
+                                   "pose, frame_ids %s, 4 scales, automask, Adam, %s"
+                                   % ("configs[1]: " if (args.height, args.width, args.num_layers, args.amp,
+                                                         args.frame_ids) == (192, 640, 18, "none", "0 -1 1") else "",
+                                      args.height, args.width, args.batch, args.num_layers, args.num_layers,
+                                      str(frame_ids).replace(" ", ""), "fp32" if args.amp == "none" else "bf16 nets"),
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world},
             "final_loss": loss_val,
         }
         if not args.no_roofline and world == 1:
-            k = time_kernels(device, args.batch, opt.height, opt.width, 2)
+            k = time_kernels(device, args.batch, opt.height, opt.width, len(frame_ids) - 1)
             dom = max(k, key=lambda n: k[n]["ms"])
             for n in k:
                 k[n]["GBs"] = k[n]["bytes"] / (k[n]["ms"] * 1e-3) / 1e9
-            kname = {"fwd": "mdx::photometric_fwd_coef_kernel<2>", "bwd": "mdx::photometric_bwd_coef_kernel<2>"}
+            nS = len(frame_ids) - 1
+            kname = {"fwd": "mdx::photometric_fwd_coef_kernel<%d>" % nS, "bwd": "mdx::photometric_bwd_coef_kernel<%d>" % nS}
             # HBM-side bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE are
             # collected in separate runs of tools/kbench.py; see profiles/r01_kernel_pmc.txt), null if absent
             traffic = {}
