@@ -16,6 +16,7 @@
 //            fixed-order pass: deterministic).
 // IDENT = true evaluates the identity (auto-mask) losses: stage 1 is replaced by loading the un-warped
 // source tiles (processor.py:187-191).
+#include <type_traits>
 #include "photo_common.hpp"
 
 namespace mdx {
@@ -118,43 +119,51 @@ MDX_DEV void photometric_fwd_body(const FwdArgs &a)
         const float *disp_b = a.disp + (size_t)b * d.h * d.w;
         const float *invK_b = a.invK + b * 16;
         const Norm2 nd = desc_norm(d);
-        HaloPx hp[NPIX];
-        PixelGeom g[NPIX];
-#pragma unroll
-        for (int k = 0; k < NPIX; ++k) {
-            hp[k] = halo_px(tid + k * NT, x0, y0, H, W);
-            float up;
-            if (same_res) up = s_d[hp[k].ly][hp[k].lx];
-            else if (reg.staged) up = upsample_staged(&s_d[0][0], reg, d, hp[k].py, hp[k].px);
-            else up = upsample_at(disp_b, d.h, d.w, H, W, hp[k].py, hp[k].px, (d.flags & MDX_FLAG_UPSAMPLE_PREMUL) != 0);
-            g[k] = geom_from_disp(d, up, invK_b, hp[k].px, hp[k].py);
-            if (a.depth && hp[k].interior) at32(a.depth + (size_t)b * HW, (unsigned)(hp[k].py * W + hp[k].px)) = g[k].depth;
-        }
-#pragma unroll
-        for (int f = 0; f < S; ++f) {
-            const float *Pf = a.P + ((size_t)f * d.B + b) * 12;
-            Tap t[NPIX];
-#pragma unroll
-            for (int k = 0; k < NPIX; ++k) {
-                const Proj pr = project_point(Pf, g[k].X0, g[k].X1, g[k].X2, 1.0f, nd, 1e-7f);
-                t[k] = make_tap(pr.gx, pr.gy, H, W);
+        // The tile + halo holds FX*FY = 660 pixels = 2 full rounds of the block plus 148: only the waves that own
+        // part of that remainder run a third pixel (wave-uniform choice, so it is a scalar branch)
+        auto warp_stage = [&](auto np_tag) {
+            constexpr int NP = decltype(np_tag)::value;
+            HaloPx hp[NP];
+            PixelGeom g[NP];
+    #pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                hp[k] = halo_px(tid + k * NT, x0, y0, H, W);
+                float up;
+                if (same_res) up = s_d[hp[k].ly][hp[k].lx];
+                else if (reg.staged) up = upsample_staged(&s_d[0][0], reg, d, hp[k].py, hp[k].px);
+                else up = upsample_at(disp_b, d.h, d.w, H, W, hp[k].py, hp[k].px, (d.flags & MDX_FLAG_UPSAMPLE_PREMUL) != 0);
+                g[k] = geom_from_disp(d, up, invK_b, hp[k].px, hp[k].py);
+                if (a.depth && hp[k].interior) at32(a.depth + (size_t)b * HW, (unsigned)(hp[k].py * W + hp[k].px)) = g[k].depth;
             }
-            Corners cn[NPIX][3];
-#pragma unroll
-            for (int k = 0; k < NPIX; ++k)
-#pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    cn[k][c] = load_corners(a.src.img[f] + ((size_t)b * 3 + c) * HW, H, W, t[k]);
-#pragma unroll
-            for (int k = 0; k < NPIX; ++k)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const float v = sample(cn[k][c], t[k]);
-                    if (hp[k].valid) s_x[f][c][hp[k].ly][hp[k].lx] = v;
-                    if (a.warp && !wide && hp[k].interior)
-                        at32(a.warp + (((size_t)f * d.B + b) * 3 + c) * HW, (unsigned)(hp[k].py * W + hp[k].px)) = v;
+    #pragma unroll
+            for (int f = 0; f < S; ++f) {
+                const float *Pf = a.P + ((size_t)f * d.B + b) * 12;
+                Tap t[NP];
+    #pragma unroll
+                for (int k = 0; k < NP; ++k) {
+                    const Proj pr = project_point(Pf, g[k].X0, g[k].X1, g[k].X2, 1.0f, nd, 1e-7f);
+                    t[k] = make_tap(pr.gx, pr.gy, H, W);
                 }
-        }
+                Corners cn[NP][3];
+    #pragma unroll
+                for (int k = 0; k < NP; ++k)
+    #pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        cn[k][c] = load_corners(a.src.img[f] + ((size_t)b * 3 + c) * HW, H, W, t[k]);
+    #pragma unroll
+                for (int k = 0; k < NP; ++k)
+    #pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const float v = sample(cn[k][c], t[k]);
+                        if (hp[k].valid) s_x[f][c][hp[k].ly][hp[k].lx] = v;
+                        if (a.warp && !wide && hp[k].interior)
+                            at32(a.warp + (((size_t)f * d.B + b) * 3 + c) * HW, (unsigned)(hp[k].py * W + hp[k].px)) = v;
+                    }
+            }
+        };
+        const int third = __builtin_amdgcn_readfirstlane((tid & ~63) + (NPIX - 1) * NT < FX * FY);
+        if (third) warp_stage(std::integral_constant<int, NPIX>{});
+        else warp_stage(std::integral_constant<int, NPIX - 1>{});
         __syncthreads();
         // warped colours of the tile -> HBM as 16-byte stores (kept for the backward kernel)
         if (a.warp && wide) {
