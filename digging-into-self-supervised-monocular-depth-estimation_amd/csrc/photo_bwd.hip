@@ -313,8 +313,14 @@ __global__ __launch_bounds__(NT, 3) void photometric_bwd_coef_kernel(BwdArgs a)
     const int tx = tid & 63;
     const int px = x0 + tx;
     float gdepth[ROWSB];
+    PixelGeom geo[ROWSB];   // frame-independent part of the geometry, once per row
 #pragma unroll
-    for (int q = 0; q < ROWSB; ++q) gdepth[q] = 0.f;
+    for (int q = 0; q < ROWSB; ++q) {
+        gdepth[q] = 0.f;
+        const int py = y0 + ROWSB * (tid >> 6) + q;
+        const bool ok = px < W && py < H;
+        geo[q] = pixel_geom(d, disp_b, invK_b, ok ? px : 0, ok ? py : 0);
+    }
     // frame by frame (rolled loop: one frame's taps, colours and sums live at a time -- 3 blocks/CU would
     // otherwise spill), both rows of this thread inside
 #pragma unroll 1
@@ -351,7 +357,7 @@ __global__ __launch_bounds__(NT, 3) void photometric_bwd_coef_kernel(BwdArgs a)
                 yq[c] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.target + ((size_t)b * 3 + c) * HW) + pb);
                 xq[c] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(warp_b + c * HW) + pb);
             }
-            const PixelGeom g = pixel_geom(d, disp_b, invK_b, px, py);
+            const PixelGeom &g = geo[q];
             const Proj pr = project_point(Pf, g.X0, g.X1, g.X2, 1.0f, nd, 1e-7f);
             const Tap t = make_tap(pr.gx, pr.gy, H, W);
             Corners cn[3];
