@@ -219,6 +219,8 @@ def main():
     ap.add_argument("--frame-ids", type=str, default="0 -1 1", help='e.g. "0 -1 1 s" for mono+stereo (configs[4])')
     ap.add_argument("--channels-last", action="store_true", help="NHWC activations/weights for the conv nets")
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark (MIOpen find mode)")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture the whole step (nets + fused loss + Adam) into ONE hipGraph and replay it (1 GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -268,12 +270,35 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    graph = None
+    if args.graph and world == 1:
+        # hipGraph: warm up on a side stream (MIOpen picks its kernels, the allocator settles), capture one step,
+        # then every timed step is a single graph launch -- ~1600 kernel launches leave the host's critical path
+        for g in optim.param_groups:
+            g["capturable"] = True
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(args.warmup, 3)):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_loss = step()
+        torch.cuda.synchronize()
+
+        def run():
+            graph.replay()
+            return static_loss
+    else:
+        run = step
+        for _ in range(args.warmup):
+            step()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step()
+        loss = run()
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -295,7 +320,7 @@ def main():
                                       args.height, args.width, args.batch, args.num_layers, args.num_layers,
                                       str(frame_ids).replace(" ", ""), "fp32" if args.amp == "none" else "bf16 nets"),
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world},
-            "final_loss": loss_val,
+            "final_loss": loss_val, "hip_graph": bool(graph is not None),
         }
         if not args.no_roofline and world == 1:
             k = time_kernels(device, args.batch, opt.height, opt.width, len(frame_ids) - 1)
