@@ -340,4 +340,21 @@ MDX_DEV float wave_sum(float v)
     return v;
 }
 
+// wave64 sum that stays in the VALU (no ds_bpermute): row_shr 1/2/4/8 inside the four 16-lane rows, then
+// row_bcast:15 and row_bcast:31 across rows.  The total is valid in lane 63 only.  Every lane of the wave must be
+// active at the call.
+MDX_DEV float wave_sum_dpp_lane63(float v)
+{
+#define MDX_DPP_STEP(ctrl, rowmask) \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rowmask, 0xf, true))
+    MDX_DPP_STEP(0x111, 0xf);
+    MDX_DPP_STEP(0x112, 0xf);
+    MDX_DPP_STEP(0x114, 0xf);
+    MDX_DPP_STEP(0x118, 0xf);
+    MDX_DPP_STEP(0x142, 0xa);
+    MDX_DPP_STEP(0x143, 0xc);
+#undef MDX_DPP_STEP
+    return v;
+}
+
 }  // namespace mdx

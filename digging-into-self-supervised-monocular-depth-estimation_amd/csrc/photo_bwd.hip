@@ -277,11 +277,11 @@ __global__ __launch_bounds__(NT, MDX_BWD_WAVES) void photometric_bwd_kernel(BwdA
 template <int S>
 __global__ __launch_bounds__(NT, 3) void photometric_bwd_coef_kernel(BwdArgs a)
 {
-    constexpr int N_ABG = 9 * FY * FX, N_SEL = (FY * FX + 3) / 4, N_RED = S * 12 * NT;
-    __shared__ float pool[N_ABG + N_SEL + N_RED];
+    constexpr int N_ABG = 9 * FY * FX, N_SEL = (FY * FX + 3) / 4;
+    __shared__ float pool[N_ABG + N_SEL];
+    __shared__ float s_red[NT / 64][S * 12];                                                // d(P): one row per wave
     float(*s_abg)[FY][FX] = reinterpret_cast<float(*)[FY][FX]>(pool);                      // [3*channel + {a,b,g}]
     signed char(*s_sel)[FX] = reinterpret_cast<signed char(*)[FX]>(pool + N_ABG);          // frame or -1
-    float *s_red = pool + N_ABG + N_SEL;                                                    // d(P) partials
 
     const mdx_desc &d = a.d;
     const int H = d.H, W = d.W;
@@ -401,8 +401,12 @@ __global__ __launch_bounds__(NT, 3) void photometric_bwd_coef_kernel(BwdArgs a)
                 accP[8 + j] += gq2 * X[j];
             }
         }
+        // wave totals in registers (DPP), lane 63 parks them for the cross-wave sum below
 #pragma unroll
-        for (int k = 0; k < 12; ++k) s_red[(f * 12 + k) * NT + tid] = accP[k];
+        for (int k = 0; k < 12; ++k) {
+            const float t = wave_sum_dpp_lane63(accP[k]);
+            if ((tid & 63) == 63) s_red[tid >> 6][f * 12 + k] = t;
+        }
     }
 #pragma unroll
     for (int q = 0; q < ROWSB; ++q) {
@@ -410,14 +414,10 @@ __global__ __launch_bounds__(NT, 3) void photometric_bwd_coef_kernel(BwdArgs a)
         if (px < W && py < H) a.gup[(size_t)b * HW + (size_t)py * W + px] = gdepth[q] * g_scale;
     }
 
-    // ---- d(P): block reduction through LDS ----
+    // ---- d(P): the four wave totals, fixed order ----
     __syncthreads();
-    for (int v = tid >> 6; v < S * 12; v += NT / 64) {
-        const float *pp = s_red + v * NT + (tid & 63);
-        float t = (pp[0] + pp[64]) + (pp[128] + pp[192]);
-        t = wave_sum(t);
-        if ((tid & 63) == 0) a.partP[(size_t)tile.linear * (S * 12) + v] = t;
-    }
+    if (tid < S * 12)
+        a.partP[(size_t)tile.linear * (S * 12) + tid] = (s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid]);
 }
 
 // d(P)[f,b,:] = g * sum over the tiles of image b: one wave64 per output element, fixed order
