@@ -219,6 +219,7 @@ def main():
     ap.add_argument("--frame-ids", type=str, default="0 -1 1", help='e.g. "0 -1 1 s" for mono+stereo (configs[4])')
     ap.add_argument("--channels-last", action="store_true", help="NHWC activations/weights for the conv nets")
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark (MIOpen find mode)")
+    ap.add_argument("--no-miopen-db", action="store_true", help="ignore the shipped gfx950 find-db (MIOpen heuristics)")
     ap.add_argument("--graph", action="store_true",
                     help="capture the whole step (nets + fused loss + Adam) into ONE hipGraph and replay it (1 GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -239,7 +240,8 @@ def main():
             torch.distributed.init_process_group("nccl", device_id=torch.device(device))
         else:
             torch.distributed.init_process_group(backend)
-    importlib.import_module("digging-into-self-supervised-monocular-depth-estimation_amd")
+    pkg = importlib.import_module("digging-into-self-supervised-monocular-depth-estimation_amd")
+    miopen_db = None if args.no_miopen_db else pkg.install_miopen_db(rank)   # tuned conv solvers (gfx950 find-db)
     from model_tool import setting, compute
 
     torch.manual_seed(1234 + rank)
@@ -320,7 +322,7 @@ def main():
                                       args.height, args.width, args.batch, args.num_layers, args.num_layers,
                                       str(frame_ids).replace(" ", ""), "fp32" if args.amp == "none" else "bf16 nets"),
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world},
-            "final_loss": loss_val, "hip_graph": bool(graph is not None),
+            "final_loss": loss_val, "hip_graph": bool(graph is not None), "miopen_find_db": bool(miopen_db),
         }
         if not args.no_roofline and world == 1:
             k = time_kernels(device, args.batch, opt.height, opt.width, len(frame_ids) - 1)

@@ -23,3 +23,9 @@ def build(force=False, verbose=False):
     """Compile libmdx_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     from build import build as _build  # noqa: resolved through PACKAGE_DIR
     return _build(force=force, verbose=verbose)
+
+
+def install_miopen_db(rank=None):
+    """See mdx/tuning.py: tuned MIOpen find-db for the networks of this path (gfx950)."""
+    from mdx.tuning import install_miopen_db as _install
+    return _install(rank)

@@ -27,6 +27,8 @@ class trainer(object):
         if world > 1 and not torch.distributed.is_initialized():
             torch.distributed.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
         self.rank = int(os.environ.get("RANK", "0"))
+        from mdx.tuning import install_miopen_db
+        install_miopen_db(self.rank)          # tuned conv solvers for the default shapes; other shapes: find mode below
         torch.backends.cudnn.benchmark = True
         self.setting = setting(opt, self.device)
         self.compute = compute(opt, self.device)
