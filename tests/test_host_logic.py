@@ -1,6 +1,7 @@
 """CPU: host-side mirror of the reference interface -- networks (shapes, state-dict keys), pose matrices
 against golden vectors, options, the synthetic data contract, metrics."""
 import importlib
+import os
 import types
 
 import numpy as np
@@ -133,3 +134,23 @@ def test_pose_driver_pair_ordering_and_invert_flag():
     aa, tr = torch.full((1, 1, 3), 0.01), torch.full((1, 1, 3), 0.02)
     np.testing.assert_allclose(out[("c2c", -1, 0)].numpy(), param2matrix(aa, tr, True).numpy())
     np.testing.assert_allclose(out[("c2c", 1, 0)].numpy(), param2matrix(aa, tr, False).numpy())
+
+
+def test_miopen_find_db_install(tmp_path, monkeypatch):
+    """mdx/tuning.py: a private writable copy of the shipped gfx950 find-db per rank; explicit env wins; opt-out."""
+    import tempfile
+    from mdx import tuning
+    monkeypatch.delenv("MIOPEN_USER_DB_PATH", raising=False)
+    monkeypatch.setattr(tempfile, "tempdir", str(tmp_path))
+    d = tuning.install_miopen_db(rank=3)
+    assert d.endswith("_r3") and os.environ["MIOPEN_USER_DB_PATH"] == d
+    shipped = sorted(f for f in os.listdir(os.path.join(tuning.PACKAGE_DIR, "miopen_db")) if f.endswith(".txt"))
+    assert shipped and sorted(os.listdir(d)) == shipped
+    for name in shipped:   # MIOpen's text format: one "key=value" record per line, keyed by gfx950
+        assert name.startswith(("gfx950", "batchnorm_gfx950"))
+        with open(os.path.join(d, name)) as fh:
+            assert all("=" in line for line in fh if line.strip())
+    assert tuning.install_miopen_db(rank=0) == d            # explicit MIOPEN_USER_DB_PATH is respected
+    monkeypatch.delenv("MIOPEN_USER_DB_PATH")
+    monkeypatch.setenv("MDX_MIOPEN_DB", "0")
+    assert tuning.install_miopen_db(rank=0) is None and "MIOPEN_USER_DB_PATH" not in os.environ
