@@ -89,7 +89,6 @@ def time_kernels(device, B, H, W, S, reps=20):
             lo = torch.randn(B, 1, max(H // 32, 2), max(W // 32, 2), generator=g)   # network-like smooth field
             disp = torch.sigmoid(torch.nn.functional.interpolate(lo, size=(h, w), mode="bilinear",
                                                                  align_corners=False)).contiguous().to(device)
-            warp = torch.empty(S, B, 3, H, W, device=device)
             coef = torch.empty(B, 9, H, W, device=device)
             d = _lib.make_desc(B, H, W, h, w, S, True, 0.1, 100.0)
             nws = lib.mdx_photometric_workspace_bytes(C.byref(d))
@@ -100,13 +99,13 @@ def time_kernels(device, B, H, W, S, reps=20):
             def fwd():
                 _lib.check(lib.mdx_photometric_fwd(
                     C.byref(d), _lib.ptr(disp), _lib.ptr(tgt), C.byref(src), _lib.ptr(invK), _lib.ptr(P),
-                    _lib.ptr(ident), _lib.ptr(noise), _lib.ptr(idx, torch.uint8), None, None, None, _lib.ptr(warp),
+                    _lib.ptr(ident), _lib.ptr(noise), _lib.ptr(idx, torch.uint8), None, None, None, None,
                     None, _lib.ptr(coef), _lib.ptr(ws, torch.float64), C.c_size_t(nws), _lib.stream()), "fwd")   # training form
 
             def bwd():
                 _lib.check(lib.mdx_photometric_bwd(
                     C.byref(d), _lib.ptr(disp), _lib.ptr(tgt), C.byref(src), _lib.ptr(invK), _lib.ptr(P),
-                    _lib.ptr(idx, torch.uint8), _lib.ptr(warp), _lib.ptr(coef), C.c_float(1e-6), None, None, None,
+                    _lib.ptr(idx, torch.uint8), None, _lib.ptr(coef), C.c_float(1e-6), None, None, None,
                     _lib.ptr(ws, torch.float64), C.c_size_t(nws), _lib.stream()), "bwd")   # fused kernel alone
             fwd()
             fn = fwd if name == "fwd" else bwd

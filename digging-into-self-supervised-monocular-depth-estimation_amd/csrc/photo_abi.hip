@@ -259,7 +259,6 @@ MDX_EXPORT int mdx_photometric_bwd(const mdx_desc *d, const float *disp, const f
     const bool same = !raw && (d->h == d->H && d->w == d->W);
     BwdArgs a = {};
     a.d = *d; a.disp = disp; a.target = target; a.src = *src; a.invK = invK; a.P = P; a.idx = idx;
-    if (coef && !warp) return MDX_ERR_NULL_POINTER;   // the coefficient path also reads the warped colours
     a.warp = warp; a.coef = coef; a.g_const = g_const; a.g_dev = g_dev;
     a.partP = (float *)((char *)workspace + ws_off_partP(d));
     a.gup = same ? gdisp : (float *)((char *)workspace + ws_off_gup(d));

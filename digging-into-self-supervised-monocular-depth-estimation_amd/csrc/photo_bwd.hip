@@ -269,14 +269,13 @@ __global__ __launch_bounds__(NT, MDX_BWD_WAVES) void photometric_bwd_kernel(BwdA
 
 // ---------------------------------------------------------------------------------------------
 // Coefficient path: the training forward already emitted, per pixel, the (alpha, beta, gamma) maps of its
-// arg-min frame (photo_fwd.hip, COEF) and the warped colours.  What is left for the backward is phase C only:
+// arg-min frame (photo_fwd.hip, COEF).  What is left for the backward is phase C only:
 // nine coefficient planes on the 1-pixel halo -> LDS (16-byte loads), one barrier, then per pixel the 3x3
 // gather with the reflection-pad fold, the L1 term, and the grid_sample / projection / depth chain.
 // No window statistics, no channel passes, no re-warp: ~60 % fewer instructions than the kernel above.
 // ---------------------------------------------------------------------------------------------
 template <int S>
-// S <= 2 fits 4 blocks/CU with a 9-dword spill and gains ~3 %; S >= 3 is faster unspilled at 3
-__global__ __launch_bounds__(NT, S <= 2 ? 4 : 3) void photometric_bwd_coef_kernel(BwdArgs a)
+__global__ __launch_bounds__(NT, 3) void photometric_bwd_coef_kernel(BwdArgs a)
 {
     constexpr int N_ABG = 9 * FY * FX, N_SEL = (FY * FX + 3) / 4;
     __shared__ float pool[N_ABG + N_SEL];
@@ -295,26 +294,13 @@ __global__ __launch_bounds__(NT, S <= 2 ? 4 : 3) void photometric_bwd_coef_kerne
     const bool automask = (d.flags & MDX_FLAG_AUTOMASK) != 0;
     const Norm2 nd = desc_norm(d);
 
-#pragma unroll
-    for (int k = 0; k < 9; ++k) load_plane_tile<1>(s_abg[k], a.coef + ((size_t)b * 9 + k) * HW, H, W, x0, y0, tid);
-    for (int i = tid; i < FX * FY; i += NT) {
-        const int ly = i / FX, lx = i - ly * FX;
-        const int px = x0 + lx - 1, py = y0 + ly - 1;
-        int f = -1;
-        if (px >= 0 && px < W && py >= 0 && py < H) {
-            const int sel = a.idx[(size_t)b * HW + (size_t)py * W + px];
-            f = automask ? sel - S : sel;
-            if (f < 0 || f >= S) f = -1;
-        }
-        s_sel[ly][lx] = (signed char)f;
-    }
-    __syncthreads();
-
     const float g_scale = a.g_const * (a.g_dev ? a.g_dev[0] : 1.0f);
     const int tx = tid & 63;
     const int px = x0 + tx;
     float gdepth[ROWSB];
-    PixelGeom geo[ROWSB];   // frame-independent part of the geometry, once per row
+    // frame-independent part of the geometry, once per row; its disparity taps are the first loads of the block so
+    // the arithmetic behind them overlaps the staging traffic below
+    PixelGeom geo[ROWSB];
 #pragma unroll
     for (int q = 0; q < ROWSB; ++q) {
         gdepth[q] = 0.f;
@@ -322,13 +308,27 @@ __global__ __launch_bounds__(NT, S <= 2 ? 4 : 3) void photometric_bwd_coef_kerne
         const bool ok = px < W && py < H;
         geo[q] = pixel_geom(d, disp_b, invK_b, ok ? px : 0, ok ? py : 0);
     }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) load_plane_tile<1>(s_abg[k], a.coef + ((size_t)b * 9 + k) * HW, H, W, x0, y0, tid);
+    for (int i = tid; i < FX * FY; i += NT) {
+        const int ly = i / FX, lx = i - ly * FX;
+        const int hx = x0 + lx - 1, hy = y0 + ly - 1;
+        int f = -1;
+        if (hx >= 0 && hx < W && hy >= 0 && hy < H) {
+            const int sel = a.idx[(size_t)b * HW + (size_t)hy * W + hx];
+            f = automask ? sel - S : sel;
+            if (f < 0 || f >= S) f = -1;
+        }
+        s_sel[ly][lx] = (signed char)f;
+    }
+    __syncthreads();
+
     // frame by frame (rolled loop: one frame's taps, colours and sums live at a time -- 3 blocks/CU would
     // otherwise spill), both rows of this thread inside
 #pragma unroll 1
     for (int f = 0; f < S; ++f) {
         const float *Pf = a.P + ((size_t)f * d.B + b) * 12;
         const float *src_b = a.src.img[f] + (size_t)b * 3 * HW;
-        const float *warp_b = a.warp + ((size_t)f * d.B + b) * 3 * HW;
         float accP[12];
 #pragma unroll
         for (int k = 0; k < 12; ++k) accP[k] = 0.f;
@@ -352,12 +352,10 @@ __global__ __launch_bounds__(NT, S <= 2 ? 4 : 3) void photometric_bwd_coef_kerne
             if (!any) continue;
             const bool centre = s_sel[r + 1][tx + 1] == f;
             const unsigned pb = (unsigned)(py * W + px) * 4u;   // byte offset inside a plane
-            float yq[3], xq[3];
+            float yq[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
+            for (int c = 0; c < 3; ++c)
                 yq[c] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.target + ((size_t)b * 3 + c) * HW) + pb);
-                xq[c] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(warp_b + c * HW) + pb);
-            }
             const PixelGeom &g = geo[q];
             const Proj pr = project_point(Pf, g.X0, g.X1, g.X2, 1.0f, nd, 1e-7f);
             const Tap t = make_tap(pr.gx, pr.gy, H, W);
@@ -366,20 +364,29 @@ __global__ __launch_bounds__(NT, S <= 2 ? 4 : 3) void photometric_bwd_coef_kerne
             for (int c = 0; c < 3; ++c) cn[c] = load_corners(src_b + c * HW, H, W, t);
             const float dy1 = (float)(t.y0 + 1) - t.iy, dy0 = t.iy - (float)t.y0;
             const float dx1 = (float)(t.x0 + 1) - t.ix, dx0 = t.ix - (float)t.x0;
-            float gu = 0.f, gv = 0.f;
+            // 3x3 coefficient sums from LDS first: they do not need the gathers, which are still in flight
+            float gA[3], gB[3], gC[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                float gA = 0.f, gB = 0.f, gC = 0.f;
+                gA[c] = 0.f; gB[c] = 0.f; gC[c] = 0.f;
                 const float *pa = &s_abg[0][0][0] + (3 * c) * FY * FX + r * FX + tx;
 #pragma unroll
                 for (int k = 0; k < 9; ++k) {
                     const int o = (k / 3) * FX + k % 3;
-                    gA = __builtin_fmaf(mk[k], pa[o], gA);
-                    gB = __builtin_fmaf(mk[k], pa[FY * FX + o], gB);
-                    gC = __builtin_fmaf(mk[k], pa[2 * FY * FX + o], gC);
+                    gA[c] = __builtin_fmaf(mk[k], pa[o], gA[c]);
+                    gB[c] = __builtin_fmaf(mk[k], pa[FY * FX + o], gB[c]);
+                    gC[c] = __builtin_fmaf(mk[k], pa[2 * FY * FX + o], gC[c]);
                 }
-                float gx = (gA + 2.0f * xq[c] * gB + yq[c] * gC) * (1.0f / 9.0f);
-                if (centre) gx -= 0.05f * ((yq[c] > xq[c]) ? 1.f : ((yq[c] < xq[c]) ? -1.f : 0.f));   // 0.15*mean_c|y-x|
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep the sums above the first use of a gathered corner
+            float gu = 0.f, gv = 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                // the warped colour of the pixel itself: the corners are here for the gradient anyway, so it is
+                // re-sampled (bit-identical to the forward's value) instead of being stored and re-read
+                const float xq = sample(cn[c], t);
+                float gx = (gA[c] + 2.0f * xq * gB[c] + yq[c] * gC[c]) * (1.0f / 9.0f);
+                if (centre) gx -= 0.05f * ((yq[c] > xq) ? 1.f : ((yq[c] < xq) ? -1.f : 0.f));   // 0.15*mean_c|y-x|
                 gu += gx * ((cn[c].ne - cn[c].nw) * dy1 + (cn[c].se - cn[c].sw) * dy0);
                 gv += gx * ((cn[c].sw - cn[c].nw) * dx1 + (cn[c].se - cn[c].ne) * dx0);
             }
@@ -443,7 +450,7 @@ int launch_photometric_bwd(const BwdArgs &a, hipStream_t st)
     const dim3 grid = tile_grid(&a.d);
 #define MDX_BWD_CASE(SS)                                                                                  \
     case SS:                                                                                              \
-        if (a.warp && a.coef) hipLaunchKernelGGL((photometric_bwd_coef_kernel<SS>), grid, dim3(NT), 0, st, a); \
+        if (a.coef) hipLaunchKernelGGL((photometric_bwd_coef_kernel<SS>), grid, dim3(NT), 0, st, a); \
         else if (a.warp) hipLaunchKernelGGL((photometric_bwd_kernel<SS, true>), grid, dim3(NT), 0, st, a);     \
         else hipLaunchKernelGGL((photometric_bwd_kernel<SS, false>), grid, dim3(NT), 0, st, a);           \
         break;

@@ -87,16 +87,19 @@ class _PhotometricScale(torch.autograd.Function):
         loss_sum = torch.empty(1, device=dev, dtype=torch.float32)
         to_opt = torch.empty(B, H, W, device=dev, dtype=torch.float32) if cfg.get("need_to_opt") else None
         depth = torch.empty(B, 1, H, W, device=dev, dtype=torch.float32) if cfg.get("need_depth") else None
-        # training keeps the warped colours for the backward kernel (35 MB per scale at B=12: cheaper to
-        # re-read than to re-warp the 2-pixel halo); cfg["save_warp"] = False restores the recompute path
-        keep_warp = cfg.get("save_warp", True) and (disp.requires_grad or P.requires_grad)
+        # What training keeps for the backward kernel (cfg):
+        #   save_coef (default)  the SSIM coefficient maps of each pixel's arg-min frame (53 MB per scale at B=12):
+        #                        the backward is then the 3x3 gather + geometry chain only, and re-samples the warped
+        #                        colour of a pixel from the corners it gathers anyway (nothing else is stored);
+        #   save_warp only       the warped colours (35 MB): the backward rebuilds the window statistics from them;
+        #   neither              the backward re-warps the 2-pixel halo.
+        keep = disp.requires_grad or P.requires_grad
+        keep_coef = keep and cfg.get("save_coef", True)
+        keep_warp = keep and cfg.get("save_warp", True) and not keep_coef
         warp = torch.empty(S, B, 3, H, W, device=dev, dtype=torch.float32) \
             if (cfg.get("need_warp") or keep_warp) else None
         reproj = torch.empty(B, S, H, W, device=dev, dtype=torch.float32) if cfg.get("need_reproj") else None
-        # ... and the SSIM coefficient maps of each pixel's arg-min frame (53 MB per scale at B=12): with them the
-        # backward kernel is the gather + geometry chain only
-        coef = torch.empty(B, 9, H, W, device=dev, dtype=torch.float32) \
-            if (keep_warp and cfg.get("save_coef", True)) else None
+        coef = torch.empty(B, 9, H, W, device=dev, dtype=torch.float32) if keep_coef else None
         nws = lib().mdx_photometric_workspace_bytes(C.byref(d))
         ws = _ws(nws, dev)
         check(lib().mdx_photometric_fwd(

@@ -94,7 +94,8 @@ size_t mdx_photometric_workspace_bytes(const mdx_desc *d);
  *          the finishing pass and leaves one double per tile at the start of the workspace;
  * optional (NULL to skip): to_opt [B,H,W]; depth [B,1,H,W]; warp [S,B,3,H,W]; reproj [B,S,H,W];
  *          coef [B,9,H,W] = the SSIM coefficient maps (alpha,beta,gamma per colour channel) of each pixel's
- *          arg-min frame, zero where an identity channel won -- hand warp and coef to mdx_photometric_bwd. */
+ *          arg-min frame, zero where an identity channel won -- hand coef (or, without it, warp) to
+ *          mdx_photometric_bwd. */
 int mdx_photometric_fwd(const mdx_desc *d, const float *disp, const float *target,
                         const mdx_sources *src, const float *invK, const float *P,
                         const float *ident, const float *noise, uint8_t *idx, float *loss_sum,
@@ -104,8 +105,9 @@ int mdx_photometric_fwd(const mdx_desc *d, const float *disp, const float *targe
 /* Backward of the above for d(loss)/d(to_optimise[b,y,x]) = g_const * (*g_dev) on every pixel
  * (g_dev may be NULL = 1).  Needs only the inputs and idx; `warp` (optional, [S,B,3,H,W]) is the forward's
  * warped-colour output -- when given the kernel reads it instead of re-warping the 2-pixel halo; `coef`
- * (optional, [B,9,H,W], needs warp) is the forward's coefficient output -- with it the backward skips the
- * window statistics altogether.
+ * (optional, [B,9,H,W]) is the forward's coefficient output -- with it the backward skips the window
+ * statistics altogether and needs no `warp` (it re-samples a pixel's own warped colour from the corners it
+ * gathers for the gradient; `warp` is ignored when `coef` is given).
  * Outputs: gdisp [B,1,h,w]; gP [S,B,3,4] (d loss / d P; chain to T with K^T outside).  Passing NULL for BOTH
  * runs the fused kernel alone and leaves its raw per-tile outputs in the workspace (timing aid). */
 int mdx_photometric_bwd(const mdx_desc *d, const float *disp, const float *target,

@@ -29,7 +29,7 @@ def main():
     ap.add_argument("--S", type=int, default=2)
     ap.add_argument("--what", type=str, default="fwd,bwd,ident,smooth")
     ap.add_argument("--save_warp", type=int, default=2,
-                    help="0: backward re-warps; 1: forward stores the warp; 2: warp + SSIM coefficient maps (training form)")
+                    help="0: backward re-warps; 1: forward stores the warp; 2: SSIM coefficient maps only (training form); 3: both")
     a = ap.parse_args()
     dev = "cuda:0"
     lib = _lib.lib()
@@ -75,14 +75,14 @@ def main():
             _lib.check(lib.mdx_photometric_fwd(
                 C.byref(d), _lib.ptr(disp), _lib.ptr(tgt), C.byref(src), _lib.ptr(invK), _lib.ptr(P),
                 _lib.ptr(ident), _lib.ptr(noise), _lib.ptr(idx, torch.uint8), None, None, None,
-                _lib.ptr(warp) if a.save_warp else None, None, _lib.ptr(coef) if a.save_warp == 2 else None,
+                _lib.ptr(warp) if a.save_warp in (1, 3) else None, None, _lib.ptr(coef) if a.save_warp >= 2 else None,
                 _lib.ptr(ws, torch.float64), C.c_size_t(nws), _lib.stream()), "fwd")
 
         def bwd():
             _lib.check(lib.mdx_photometric_bwd(
                 C.byref(d), _lib.ptr(disp), _lib.ptr(tgt), C.byref(src), _lib.ptr(invK), _lib.ptr(P),
-                _lib.ptr(idx, torch.uint8), _lib.ptr(warp) if a.save_warp else None,
-                _lib.ptr(coef) if a.save_warp == 2 else None, C.c_float(1e-6), None, _lib.ptr(gdisp), _lib.ptr(gP),
+                _lib.ptr(idx, torch.uint8), _lib.ptr(warp) if a.save_warp in (1, 3) else None,
+                _lib.ptr(coef) if a.save_warp >= 2 else None, C.c_float(1e-6), None, _lib.ptr(gdisp), _lib.ptr(gP),
                 _lib.ptr(ws, torch.float64), C.c_size_t(nws), _lib.stream()), "bwd")
 
         def ident_fn():
