@@ -192,6 +192,7 @@ struct Corners { float nw, ne, sw, se; };
 // by load INSTRUCTIONS here, not by bytes.  The pair is anchored at min(x0, W-2) so it never leaves
 // the row; the row below is clamped to H-1 and zeroed when it is out of range.  Needs W >= 2.
 typedef float float2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+typedef float float3_a4 __attribute__((ext_vector_type(3), aligned(4)));
 
 MDX_DEV Corners load_corners(const float *__restrict__ img, int H, int W, const Tap &t)
 {

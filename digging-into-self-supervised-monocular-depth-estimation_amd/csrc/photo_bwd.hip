@@ -277,11 +277,9 @@ __global__ __launch_bounds__(NT, MDX_BWD_WAVES) void photometric_bwd_kernel(BwdA
 template <int S>
 __global__ __launch_bounds__(NT, 3) void photometric_bwd_coef_kernel(BwdArgs a)
 {
-    constexpr int N_ABG = 9 * FY * FX, N_SEL = (FY * FX + 3) / 4;
-    __shared__ float pool[N_ABG + N_SEL];
-    __shared__ float s_red[NT / 64][S * 12];                                                // d(P): one row per wave
-    float(*s_abg)[FY][FX] = reinterpret_cast<float(*)[FY][FX]>(pool);                      // [3*channel + {a,b,g}]
-    signed char(*s_sel)[FX] = reinterpret_cast<signed char(*)[FX]>(pool + N_ABG);          // frame or -1
+    __shared__ float s_abg[9][FY][FX];             // [3*channel + {alpha, beta, gamma}] on the tile + 1-pixel halo
+    __shared__ signed char s_sel[FY][FX + 2];      // arg-min frame of the pixel, or -1
+    __shared__ float s_red[NT / 64][S * 12];       // d(P): one row per wave
 
     const mdx_desc &d = a.d;
     const int H = d.H, W = d.W;
@@ -308,8 +306,17 @@ __global__ __launch_bounds__(NT, 3) void photometric_bwd_coef_kernel(BwdArgs a)
         const bool ok = px < W && py < H;
         geo[q] = pixel_geom(d, disp_b, invK_b, ok ? px : 0, ok ? py : 0);
     }
-#pragma unroll
-    for (int k = 0; k < 9; ++k) load_plane_tile<1>(s_abg[k], a.coef + ((size_t)b * 9 + k) * HW, H, W, x0, y0, tid);
+    // coefficient triplets of the tile + 1-pixel halo (reflection padded): one 12-byte load per pixel and colour
+    // channel, parked as three planes (the 3x3 gather below then reads pairs of adjacent columns)
+    for (int i = tid; i < 3 * FY * FX; i += NT) {
+        const int c = i / (FY * FX), rem = i - c * (FY * FX);
+        const int ly = rem / FX, lx = rem - ly * FX;
+        const int hx = x0 + lx - 1, hy = y0 + ly - 1;
+        if (hx > W || hy > H) continue;            // beyond the reflected ring: never read
+        const unsigned o = (unsigned)(reflect(hy, H) * W + reflect(hx, W)) * 12u;
+        const float3_a4 v = *reinterpret_cast<const float3_a4 *>(reinterpret_cast<const char *>(a.coef + ((size_t)b * 3 + c) * HW * 3) + o);
+        s_abg[3 * c][ly][lx] = v.x; s_abg[3 * c + 1][ly][lx] = v.y; s_abg[3 * c + 2][ly][lx] = v.z;
+    }
     for (int i = tid; i < FX * FY; i += NT) {
         const int ly = i / FX, lx = i - ly * FX;
         const int hx = x0 + lx - 1, hy = y0 + ly - 1;
@@ -369,7 +376,7 @@ __global__ __launch_bounds__(NT, 3) void photometric_bwd_coef_kernel(BwdArgs a)
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 gA[c] = 0.f; gB[c] = 0.f; gC[c] = 0.f;
-                const float *pa = &s_abg[0][0][0] + (3 * c) * FY * FX + r * FX + tx;
+                const float *pa = &s_abg[3 * c][r][tx];
 #pragma unroll
                 for (int k = 0; k < 9; ++k) {
                     const int o = (k / 3) * FX + k % 3;

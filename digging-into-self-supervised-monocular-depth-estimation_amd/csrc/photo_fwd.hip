@@ -265,9 +265,12 @@ MDX_DEV void photometric_fwd_body(const FwdArgs &a)
                     if (fsel == f) sel = st[COEF ? f : 0][c];
                 SsimGrad sg = ssim_grad(sel, ts[c], 0.85f / 3.0f);
                 if (fsel < 0) { sg.alpha = 0.f; sg.beta = 0.f; sg.gamma = 0.f; }
-                if (valid) {
-                    float *o = a.coef + ((size_t)b * 9 + c * 3) * HW;
-                    at32(o, p) = sg.alpha; at32(o + HW, p) = sg.beta; at32(o + 2 * HW, p) = sg.gamma;
+                if (valid) {   // [B,3,H,W,3]: one 12-byte store per colour channel (a store instruction costs the
+                               // same issue slot for 4 or 12 bytes per lane)
+                    char *o = reinterpret_cast<char *>(a.coef + ((size_t)b * 3 + c) * HW * 3) + p * 12u;
+                    float3_a4 v;
+                    v.x = sg.alpha; v.y = sg.beta; v.z = sg.gamma;
+                    *reinterpret_cast<float3_a4 *>(o) = v;
                 }
             }
         }

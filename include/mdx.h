@@ -93,7 +93,8 @@ size_t mdx_photometric_workspace_bytes(const mdx_desc *d);
  *          loss_sum [1] float = sum over B,H,W of to_optimise (divide by B*H*W for .mean()); NULL skips
  *          the finishing pass and leaves one double per tile at the start of the workspace;
  * optional (NULL to skip): to_opt [B,H,W]; depth [B,1,H,W]; warp [S,B,3,H,W]; reproj [B,S,H,W];
- *          coef [B,9,H,W] = the SSIM coefficient maps (alpha,beta,gamma per colour channel) of each pixel's
+ *          coef [B,3,H,W,3] (9*B*H*W floats) = the SSIM coefficient triplets (alpha,beta,gamma) per colour
+ *          channel of each pixel's
  *          arg-min frame, zero where an identity channel won -- hand coef (or, without it, warp) to
  *          mdx_photometric_bwd. */
 int mdx_photometric_fwd(const mdx_desc *d, const float *disp, const float *target,
@@ -105,7 +106,7 @@ int mdx_photometric_fwd(const mdx_desc *d, const float *disp, const float *targe
 /* Backward of the above for d(loss)/d(to_optimise[b,y,x]) = g_const * (*g_dev) on every pixel
  * (g_dev may be NULL = 1).  Needs only the inputs and idx; `warp` (optional, [S,B,3,H,W]) is the forward's
  * warped-colour output -- when given the kernel reads it instead of re-warping the 2-pixel halo; `coef`
- * (optional, [B,9,H,W]) is the forward's coefficient output -- with it the backward skips the window
+ * (optional, [B,3,H,W,3]) is the forward's coefficient output -- with it the backward skips the window
  * statistics altogether and needs no `warp` (it re-samples a pixel's own warped colour from the corners it
  * gathers for the gradient; `warp` is ignored when `coef` is given).
  * Outputs: gdisp [B,1,h,w]; gP [S,B,3,4] (d loss / d P; chain to T with K^T outside).  Passing NULL for BOTH
