@@ -25,8 +25,12 @@ def install_miopen_db(rank=None):
         rank = int(os.environ.get("RANK", "0"))
     dst = os.path.join(tempfile.gettempdir(), "mdx_miopen_db_%d_r%d" % (os.getuid(), rank))
     os.makedirs(dst, exist_ok=True)
+    # always a pristine copy: MIOpen rewrites entries in place when a find runs, and a copy left behind by an
+    # earlier process then steers later runs by that process's noisy timings
+    for name in os.listdir(dst):
+        os.remove(os.path.join(dst, name))
     for name in os.listdir(src):
-        if name.endswith(".txt") and not os.path.exists(os.path.join(dst, name)):
+        if name.endswith(".txt"):
             shutil.copyfile(os.path.join(src, name), os.path.join(dst, name))
     os.environ["MIOPEN_USER_DB_PATH"] = dst
     return dst
