@@ -12,7 +12,9 @@ per-GPU work is fixed (weak scaling).  Prints ONE JSON line on rank 0.
 
 Extra objects in the line:
   roofline      the dominant hand-written kernel (photometric forward or backward, whichever takes longer),
-                algorithmic bytes per launch (SURVEY 8d formula) / HIP-event launch time / 8 TB/s
+                algorithmic bytes per launch (SURVEY 8d formula) / launch duration / 8 TB/s; the duration is the mean
+                over every launch of the timed steps, from HIP events the library records on the launch stream
+                right before and after the kernel (mdx_photometric_*_timed)
   cpu_baseline  the same step on the host cores: torch-CPU networks + the CPU oracle for the loss path
                 (kind "port"), on a bounded sample (batch 4, configs[0])
 """
@@ -56,72 +58,6 @@ def alg_bytes(B, H, W, S, scale, bwd=False):
     """target RGB + S source RGB (each unique byte once) + uint8 index + low-res disparity."""
     n_lo = B * (H >> scale) * (W >> scale)
     return B * H * W * (12 + 12 * S + 1) + n_lo * (8 if bwd else 4)
-
-
-def time_kernels(device, B, H, W, S, reps=20):
-    """Average launch duration of the fused forward / backward kernels over the 4 scales, measured with
-    HIP events on the stream the kernels are enqueued on (torch's current stream)."""
-    import ctypes as C
-    from mdx import _lib
-    from mdx import functional as F
-    lib = _lib.lib()
-    g = torch.Generator(device="cpu").manual_seed(0)
-    base = torch.nn.functional.interpolate(torch.rand(B, 3, H // 4, W // 4, generator=g), size=(H, W),
-                                           mode="bilinear", align_corners=False)
-    tgt = (base + 0.05 * torch.rand(B, 3, H, W, generator=g)).clamp(0, 1).to(device)
-    srcs = [(torch.roll(base, 3 * (k + 1), 3) + 0.05 * torch.rand(B, 3, H, W, generator=g)).clamp(0, 1).to(device)
-            for k in range(S)]
-    from model_tool.synthetic import make_K
-    K, invK = make_K(H, W)
-    K, invK = K.to(device).repeat(B, 1, 1), invK.to(device).repeat(B, 1, 1)
-    T = torch.eye(4, device=device).repeat(B, 1, 1)
-    T[:, :3, 3] = 0.02 * torch.randn(B, 3, generator=g).to(device)
-    P = torch.stack([F.compose_projection(K, T) for _ in range(S)])
-    ident = F.identity_loss(tgt, srcs)
-    noise = torch.randn(B, S, H, W, generator=g).to(device)
-    idx = torch.empty(B, H, W, dtype=torch.uint8, device=device)
-    src = _lib.make_sources(srcs)
-    res = {}
-    for name in ("fwd", "bwd"):
-        tot_ms, tot_bytes, launches = 0.0, 0, 0
-        for s in range(4):
-            h, w = H >> s, W >> s
-            lo = torch.randn(B, 1, max(H // 32, 2), max(W // 32, 2), generator=g)   # network-like smooth field
-            disp = torch.sigmoid(torch.nn.functional.interpolate(lo, size=(h, w), mode="bilinear",
-                                                                 align_corners=False)).contiguous().to(device)
-            coef = torch.empty(B, 9, H, W, device=device)
-            d = _lib.make_desc(B, H, W, h, w, S, True, 0.1, 100.0)
-            nws = lib.mdx_photometric_workspace_bytes(C.byref(d))
-            ws = torch.empty(nws // 8 + 1, dtype=torch.float64, device=device)
-            gdisp = torch.empty_like(disp)
-            gP = torch.empty(S, B, 3, 4, device=device)
-
-            def fwd():
-                _lib.check(lib.mdx_photometric_fwd(
-                    C.byref(d), _lib.ptr(disp), _lib.ptr(tgt), C.byref(src), _lib.ptr(invK), _lib.ptr(P),
-                    _lib.ptr(ident), _lib.ptr(noise), _lib.ptr(idx, torch.uint8), None, None, None, None,
-                    None, _lib.ptr(coef), _lib.ptr(ws, torch.float64), C.c_size_t(nws), _lib.stream()), "fwd")   # training form
-
-            def bwd():
-                _lib.check(lib.mdx_photometric_bwd(
-                    C.byref(d), _lib.ptr(disp), _lib.ptr(tgt), C.byref(src), _lib.ptr(invK), _lib.ptr(P),
-                    _lib.ptr(idx, torch.uint8), None, _lib.ptr(coef), C.c_float(1e-6), None, None, None,
-                    _lib.ptr(ws, torch.float64), C.c_size_t(nws), _lib.stream()), "bwd")   # fused kernel alone
-            fwd()
-            fn = fwd if name == "fwd" else bwd
-            for _ in range(3):
-                fn()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(reps):
-                fn()
-            e1.record()
-            e1.synchronize()
-            tot_ms += e0.elapsed_time(e1) / reps
-            tot_bytes += alg_bytes(B, H, W, S, s, bwd=(name == "bwd"))
-            launches += 1
-        res[name] = {"ms": tot_ms / launches, "bytes": tot_bytes / launches}
-    return res
 
 
 def cpu_baseline(batch=4, steps=3):
@@ -300,12 +236,26 @@ def main():
         run = step
         for _ in range(args.warmup):
             step()
+    # HIP events around every fused photometric kernel of the timed steps (recorded by the library on the launch
+    # stream, right before / after the kernel): the roofline numbers below come from the very launches that are timed
+    from mdx import functional as F
+    timing = {"fwd": [], "bwd": []} if (rank == 0 and not args.no_roofline and graph is None) else None
     fence()
+    F.TIMING = timing
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = run()
     fence()
     dt = time.perf_counter() - t0
+    F.TIMING = None
+    if rank == 0 and not args.no_roofline and graph is not None:
+        # graph replay launches no Python: time the kernels over a few eager steps after the timed region instead
+        timing = {"fwd": [], "bwd": []}
+        F.TIMING = timing
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        F.TIMING = None
     if world > 1:
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -327,8 +277,11 @@ def main():
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world},
             "final_loss": loss_val, "hip_graph": bool(graph is not None), "miopen_find_db": bool(miopen_db),
         }
-        if not args.no_roofline and world == 1:
-            k = time_kernels(device, args.batch, opt.height, opt.width, len(frame_ids) - 1)
+        if not args.no_roofline and timing is not None:
+            tsum = F.timing_summary(timing)
+            k = {n: {"ms": 1e-3 * tsum[n][0], "launches": tsum[n][1],
+                     "bytes": sum(alg_bytes(args.batch, opt.height, opt.width, len(frame_ids) - 1, sc, bwd=(n == "bwd"))
+                                  for sc in range(4)) / 4.0} for n in ("fwd", "bwd")}
             dom = max(k, key=lambda n: k[n]["ms"])
             for n in k:
                 k[n]["GBs"] = k[n]["bytes"] / (k[n]["ms"] * 1e-3) / 1e9
@@ -345,7 +298,9 @@ def main():
             line["roofline"] = {"kernel": kname[dom], "bound": "hbm",
                                 "achieved": k[dom]["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": k[dom]["GBs"] / HBM_PEAK_GBS, "traffic": traffic.get(dom),
-                                "launch_us": 1e3 * k[dom]["ms"], "alg_bytes_per_launch": k[dom]["bytes"]}
+                                "launch_us": 1e3 * k[dom]["ms"], "alg_bytes_per_launch": k[dom]["bytes"],
+                                "launches_timed": k[dom]["launches"],
+                                "timing": "HIP events recorded by the library around this kernel in the timed steps"}
             other = "fwd" if dom == "bwd" else "bwd"
             line["roofline_other"] = {"kernel": kname[other], "achieved": k[other]["GBs"],
                                       "frac": k[other]["GBs"] / HBM_PEAK_GBS, "launch_us": 1e3 * k[other]["ms"],

@@ -210,12 +210,40 @@ MDX_EXPORT size_t mdx_photometric_workspace_bytes(const mdx_desc *d)
     return validate_desc(d) ? 0 : ws_total(d);
 }
 
-MDX_EXPORT int mdx_photometric_fwd(const mdx_desc *d, const float *disp, const float *target,
-                                   const mdx_sources *src, const float *invK, const float *P,
-                                   const float *ident, const float *noise, uint8_t *idx,
-                                   float *loss_sum, float *to_opt, float *depth, float *warp,
-                                   float *reproj, float *coef, void *workspace, size_t workspace_bytes,
-                                   void *stream)
+MDX_EXPORT void *mdx_event_create(void)
+{
+    hipEvent_t e = nullptr;
+    return hipEventCreate(&e) == hipSuccess ? (void *)e : nullptr;
+}
+
+MDX_EXPORT void mdx_event_destroy(void *event)
+{
+    if (event) (void)hipEventDestroy((hipEvent_t)event);
+}
+
+MDX_EXPORT int mdx_event_elapsed_us(void *start, void *stop, float *us)
+{
+    if (!start || !stop || !us) return MDX_ERR_NULL_POINTER;
+    float ms = 0.f;
+    if (hipEventSynchronize((hipEvent_t)stop) != hipSuccess ||
+        hipEventElapsedTime(&ms, (hipEvent_t)start, (hipEvent_t)stop) != hipSuccess)
+        return MDX_ERR_LAUNCH;
+    *us = 1e3f * ms;
+    return MDX_OK;
+}
+
+static void mark(const mdx_timing *t, bool stop, hipStream_t st)
+{
+    void *e = t ? (stop ? t->stop : t->start) : nullptr;
+    if (e) (void)hipEventRecord((hipEvent_t)e, st);
+}
+
+MDX_EXPORT int mdx_photometric_fwd_timed(const mdx_desc *d, const float *disp, const float *target,
+                                         const mdx_sources *src, const float *invK, const float *P,
+                                         const float *ident, const float *noise, uint8_t *idx,
+                                         float *loss_sum, float *to_opt, float *depth, float *warp,
+                                         float *reproj, float *coef, void *workspace, size_t workspace_bytes,
+                                         void *stream, const mdx_timing *t)
 {
     int rc = validate_desc(d);
     if (rc) return rc;
@@ -231,18 +259,32 @@ MDX_EXPORT int mdx_photometric_fwd(const mdx_desc *d, const float *disp, const f
     a.d = *d; a.disp = disp; a.target = target; a.src = *src; a.invK = invK; a.P = P;
     a.ident = ident; a.noise = noise; a.idx = idx; a.to_opt = to_opt; a.depth = depth; a.warp = warp;
     a.reproj = reproj; a.coef = coef; a.partials = (double *)workspace;
+    mark(t, false, (hipStream_t)stream);
     rc = launch_photometric_fwd(a, false, (hipStream_t)stream);
+    mark(t, true, (hipStream_t)stream);
     if (rc || !loss_sum) return rc;   // loss_sum == NULL: leave the per-tile partials in the workspace
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream,
                        (const double *)workspace, (int)num_tiles(d), loss_sum);
     return check_launch();
 }
 
-MDX_EXPORT int mdx_photometric_bwd(const mdx_desc *d, const float *disp, const float *target,
+MDX_EXPORT int mdx_photometric_fwd(const mdx_desc *d, const float *disp, const float *target,
                                    const mdx_sources *src, const float *invK, const float *P,
-                                   const uint8_t *idx, const float *warp, const float *coef,
-                                   float g_const, const float *g_dev, float *gdisp, float *gP,
-                                   void *workspace, size_t workspace_bytes, void *stream)
+                                   const float *ident, const float *noise, uint8_t *idx,
+                                   float *loss_sum, float *to_opt, float *depth, float *warp,
+                                   float *reproj, float *coef, void *workspace, size_t workspace_bytes,
+                                   void *stream)
+{
+    return mdx_photometric_fwd_timed(d, disp, target, src, invK, P, ident, noise, idx, loss_sum, to_opt, depth, warp,
+                                     reproj, coef, workspace, workspace_bytes, stream, nullptr);
+}
+
+MDX_EXPORT int mdx_photometric_bwd_timed(const mdx_desc *d, const float *disp, const float *target,
+                                         const mdx_sources *src, const float *invK, const float *P,
+                                         const uint8_t *idx, const float *warp, const float *coef,
+                                         float g_const, const float *g_dev, float *gdisp, float *gP,
+                                         void *workspace, size_t workspace_bytes, void *stream,
+                                         const mdx_timing *t)
 {
     int rc = validate_desc(d);
     if (rc) return rc;
@@ -262,11 +304,24 @@ MDX_EXPORT int mdx_photometric_bwd(const mdx_desc *d, const float *disp, const f
     a.warp = warp; a.coef = coef; a.g_const = g_const; a.g_dev = g_dev;
     a.partP = (float *)((char *)workspace + ws_off_partP(d));
     a.gup = same ? gdisp : (float *)((char *)workspace + ws_off_gup(d));
-    if ((rc = launch_photometric_bwd(a, st)) || raw) return rc;
+    mark(t, false, st);
+    rc = launch_photometric_bwd(a, st);
+    mark(t, true, st);
+    if (rc || raw) return rc;
     const dim3 grid = tile_grid(d);
     if ((rc = launch_finish_gP(a.partP, d->S, d->B, (int)(grid.x * grid.y), g_const, g_dev, gP, st))) return rc;
     if (!same) rc = launch_upsample_bwd(a.gup, d->B, d->H, d->W, gdisp, d->h, d->w, st);
     return rc;
+}
+
+MDX_EXPORT int mdx_photometric_bwd(const mdx_desc *d, const float *disp, const float *target,
+                                   const mdx_sources *src, const float *invK, const float *P,
+                                   const uint8_t *idx, const float *warp, const float *coef,
+                                   float g_const, const float *g_dev, float *gdisp, float *gP,
+                                   void *workspace, size_t workspace_bytes, void *stream)
+{
+    return mdx_photometric_bwd_timed(d, disp, target, src, invK, P, idx, warp, coef, g_const, g_dev, gdisp, gP,
+                                     workspace, workspace_bytes, stream, nullptr);
 }
 
 MDX_EXPORT int mdx_interpolate_bilinear_bwd(const float *gout, int BC, int H, int W, float *gin, int h,

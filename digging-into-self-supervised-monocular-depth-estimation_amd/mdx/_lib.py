@@ -29,6 +29,10 @@ class Sources(C.Structure):
     _fields_ = [("img", C.c_void_p * MAX_SRC)]
 
 
+class Timing(C.Structure):   # mdx_timing: hipEvent_t pair recorded right before / after the fused kernel
+    _fields_ = [("start", C.c_void_p), ("stop", C.c_void_p)]
+
+
 # every symbol include/mdx.h declares: name -> restype (None = int status)
 SYMBOLS = {
     "mdx_version": C.c_int, "mdx_status_string": C.c_char_p, "mdx_desc_init": C.c_int,
@@ -42,6 +46,8 @@ SYMBOLS = {
     "mdx_grid_sample_border_fwd": C.c_int, "mdx_grid_sample_border_bwd": C.c_int,
     "mdx_reprojection_loss_fwd": C.c_int, "mdx_reprojection_loss_bwd": C.c_int, "mdx_ssim_fwd": C.c_int,
     "mdx_min_automask_fwd": C.c_int,
+    "mdx_event_create": C.c_void_p, "mdx_event_destroy": None, "mdx_event_elapsed_us": C.c_int,
+    "mdx_photometric_fwd_timed": C.c_int, "mdx_photometric_bwd_timed": C.c_int,
 }
 
 

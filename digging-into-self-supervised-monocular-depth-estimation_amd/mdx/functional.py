@@ -67,6 +67,35 @@ def identity_loss(target, sources, desc=None):
     return out
 
 
+# Measurement aid: when a dict {"fwd": [], "bwd": []}, every fused per-scale launch goes through the *_timed entry
+# points and appends its (start, stop) hipEvent pair, recorded right around the fused kernel on the launch stream;
+# timing_summary() turns them into mean microseconds.  Same kernels, same order, same results as the plain path.
+TIMING = None
+
+
+def _timing_hook(kind):
+    if TIMING is None:
+        return None
+    t = _lib.Timing(lib().mdx_event_create(), lib().mdx_event_create())
+    TIMING[kind].append(t)
+    return t
+
+
+def timing_summary(timing):
+    """{kind: (mean_us, n)} of the recorded pairs; destroys the events."""
+    out = {}
+    for kind, pairs in timing.items():
+        us = []
+        for t in pairs:
+            v = C.c_float()
+            check(lib().mdx_event_elapsed_us(C.c_void_p(t.start), C.c_void_p(t.stop), C.byref(v)), "mdx_event_elapsed_us")
+            us.append(v.value)
+            lib().mdx_event_destroy(C.c_void_p(t.start))
+            lib().mdx_event_destroy(C.c_void_p(t.stop))
+        out[kind] = (sum(us) / max(len(us), 1), len(us))
+    return out
+
+
 class _PhotometricScale(torch.autograd.Function):
     """One scale: returns (sum over pixels of to_optimise [1], idx uint8 [B,H,W], extras...)."""
 
@@ -102,12 +131,13 @@ class _PhotometricScale(torch.autograd.Function):
         coef = torch.empty(B, 9, H, W, device=dev, dtype=torch.float32) if keep_coef else None
         nws = lib().mdx_photometric_workspace_bytes(C.byref(d))
         ws = _ws(nws, dev)
-        check(lib().mdx_photometric_fwd(
+        hook = _timing_hook("fwd") if keep_coef else None
+        check(lib().mdx_photometric_fwd_timed(
             C.byref(d), ptr(disp), ptr(target), C.byref(src), ptr(invK), ptr(P),
             ptr(ident, optional=True) if automask else None, ptr(noise, optional=True) if automask else None,
             ptr(idx, torch.uint8), ptr(loss_sum), ptr(to_opt, optional=True), ptr(depth, optional=True),
             ptr(warp, optional=True), ptr(reproj, optional=True), ptr(coef, optional=True), ptr(ws, torch.float64),
-            C.c_size_t(nws), stream()), "mdx_photometric_fwd")
+            C.c_size_t(nws), stream(), C.byref(hook) if hook is not None else None), "mdx_photometric_fwd")
         ctx.save_for_backward(disp, P, target, invK, idx, *sources)
         ctx.warp = warp if keep_warp else None
         ctx.coef = coef
@@ -130,11 +160,12 @@ class _PhotometricScale(torch.autograd.Function):
         g_dev = _f32c(g_sum.reshape(1))
         nws = lib().mdx_photometric_workspace_bytes(C.byref(d))
         ws = _ws(nws, dev)
-        check(lib().mdx_photometric_bwd(
+        hook = _timing_hook("bwd") if ctx.coef is not None else None
+        check(lib().mdx_photometric_bwd_timed(
             C.byref(d), ptr(disp), ptr(target), C.byref(src), ptr(invK), ptr(P), ptr(idx, torch.uint8),
             ptr(ctx.warp, optional=True), ptr(ctx.coef, optional=True), C.c_float(1.0), ptr(g_dev), ptr(gdisp), ptr(gP),
             ptr(ws, torch.float64),
-            C.c_size_t(nws), stream()), "mdx_photometric_bwd")
+            C.c_size_t(nws), stream(), C.byref(hook) if hook is not None else None), "mdx_photometric_bwd")
         return (gdisp, gP, None, None, None, None, None) + (None,) * S
 
 

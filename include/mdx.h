@@ -103,6 +103,22 @@ int mdx_photometric_fwd(const mdx_desc *d, const float *disp, const float *targe
                         float *to_opt, float *depth, float *warp, float *reproj, float *coef,
                         void *workspace, size_t workspace_bytes, void *stream);
 
+/* Measurement hook: a pair of hipEvent_t handles that the *_timed entry points record on `stream` immediately
+ * before and immediately after the FUSED kernel of the call (not around its small finishing passes), so that a
+ * caller can time that kernel inside a real training step.  mdx_event_* are thin wrappers over hipEventCreate /
+ * hipEventDestroy / hipEventSynchronize + hipEventElapsedTime for callers without a HIP binding. */
+typedef struct mdx_timing { void *start, *stop; } mdx_timing;
+void *mdx_event_create(void);
+void mdx_event_destroy(void *event);
+int mdx_event_elapsed_us(void *start, void *stop, float *us);   /* waits for `stop` */
+
+/* mdx_photometric_fwd / mdx_photometric_bwd with the hook (t == NULL: exactly the plain call). */
+int mdx_photometric_fwd_timed(const mdx_desc *d, const float *disp, const float *target,
+                              const mdx_sources *src, const float *invK, const float *P,
+                              const float *ident, const float *noise, uint8_t *idx, float *loss_sum,
+                              float *to_opt, float *depth, float *warp, float *reproj, float *coef,
+                              void *workspace, size_t workspace_bytes, void *stream, const mdx_timing *t);
+
 /* Backward of the above for d(loss)/d(to_optimise[b,y,x]) = g_const * (*g_dev) on every pixel
  * (g_dev may be NULL = 1).  Needs only the inputs and idx; `warp` (optional, [S,B,3,H,W]) is the forward's
  * warped-colour output -- when given the kernel reads it instead of re-warping the 2-pixel halo; `coef`
@@ -116,6 +132,11 @@ int mdx_photometric_bwd(const mdx_desc *d, const float *disp, const float *targe
                         const uint8_t *idx, const float *warp, const float *coef, float g_const,
                         const float *g_dev, float *gdisp, float *gP, void *workspace, size_t workspace_bytes,
                         void *stream);
+int mdx_photometric_bwd_timed(const mdx_desc *d, const float *disp, const float *target,
+                        const mdx_sources *src, const float *invK, const float *P,
+                        const uint8_t *idx, const float *warp, const float *coef, float g_const,
+                        const float *g_dev, float *gdisp, float *gP, void *workspace, size_t workspace_bytes,
+                        void *stream, const mdx_timing *t);
 
 /* Edge-aware smoothness   replaces model_loss.py:77-88,112-115 (processor.py:208).
  * disp [B,1,h,w], color [B,3,h,w] -> loss [1]; gdisp (optional) = d loss / d disp for unit upstream.
