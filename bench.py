@@ -155,6 +155,8 @@ def main():
     ap.add_argument("--channels-last", action="store_true", help="NHWC activations/weights for the conv nets")
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark (MIOpen find mode)")
     ap.add_argument("--no-miopen-db", action="store_true", help="ignore the shipped gfx950 find-db (MIOpen heuristics)")
+    ap.add_argument("--no-miopen-find", action="store_true",
+                    help="immediate mode even for the tuned shapes (use under rocprofv3: MIOpen re-runs its find there)")
     ap.add_argument("--graph", action="store_true",
                     help="capture the whole step (nets + fused loss + Adam) into ONE hipGraph and replay it (1 GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -188,7 +190,7 @@ def main():
     # several minutes otherwise -- so it is on by default only for the tuned shapes
     tuned = bool(miopen_db) and (args.batch, args.height, args.width, args.num_layers) == (12, 192, 640, 18) \
         and not args.channels_last
-    torch.backends.cudnn.benchmark = args.miopen_find or tuned
+    torch.backends.cudnn.benchmark = (args.miopen_find or tuned) and not args.no_miopen_find
     st = setting(opt, device)
     cp = compute(opt, device)
     st.set_train()
