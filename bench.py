@@ -155,8 +155,6 @@ def main():
     ap.add_argument("--channels-last", action="store_true", help="NHWC activations/weights for the conv nets")
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark (MIOpen find mode)")
     ap.add_argument("--no-miopen-db", action="store_true", help="ignore the shipped gfx950 find-db (MIOpen heuristics)")
-    ap.add_argument("--no-miopen-find", action="store_true",
-                    help="immediate mode even for the tuned shapes (use under rocprofv3: MIOpen re-runs its find there)")
     ap.add_argument("--graph", action="store_true",
                     help="capture the whole step (nets + fused loss + Adam) into ONE hipGraph and replay it (1 GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -186,11 +184,10 @@ def main():
     opt = make_opt(args.batch, height=args.height, width=args.width, frame_ids=frame_ids, num_layers=args.num_layers,
                    amp=args.amp)
     opt.channels_last = args.channels_last
-    # MIOpen find mode: instant when the shipped find-db holds the shapes (the tuned flagship workload), a search of
-    # several minutes otherwise -- so it is on by default only for the tuned shapes
-    tuned = bool(miopen_db) and (args.batch, args.height, args.width, args.num_layers) == (12, 192, 640, 18) \
-        and not args.channels_last
-    torch.backends.cudnn.benchmark = (args.miopen_find or tuned) and not args.no_miopen_find
+    # MIOpen picks the tuned solvers from the shipped find-db in immediate mode already (fp32: same images/s as find
+    # mode).  Find mode proper (--miopen-find) returns at once on a db hit but searches for minutes on a miss, so it
+    # is never on by default; bf16 networks gain from it (a few more solvers are only reachable through find).
+    torch.backends.cudnn.benchmark = args.miopen_find
     st = setting(opt, device)
     cp = compute(opt, device)
     st.set_train()

@@ -12,7 +12,7 @@ if [ "$1" = "--collect" ]; then
     cd "$ROOT" || exit 1
     cp "$OUT/bench_unprofiled.json" "profiles/${tag}_bench_unprofiled.json"
     python tools/summarize_rocprof.py "$OUT/bench_stats" "profiles/${tag}_bench_kernel_stats.txt" \
-        "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-miopen-find   (MI355X, 1 GPU)" > /dev/null
+        "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline   (MI355X, 1 GPU)" > /dev/null
     python tools/summarize_rocprof.py "$OUT/kbench_stats" "profiles/${tag}_kbench_kernel_stats.txt" \
         "rocprofv3 --kernel-trace --stats --output-format csv -- python3 tools/kbench.py   (hand-written kernels only; B=12 192x640 S=2)" > /dev/null
     python tools/pmc_summary.py "profiles/${tag}_kernel_pmc.txt" "$OUT"/pmc_* > /dev/null
@@ -21,15 +21,13 @@ if [ "$1" = "--collect" ]; then
 fi
 mkdir -p "$OUT" && cd /tmp && export TMPDIR=/tmp
 if [ "$1" = "--bench-stats-only" ]; then
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_stats" -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-miopen-find > "$OUT/bench_stats.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_stats" -- python3 "$ROOT/bench.py" --no-cpu-baseline > "$OUT/bench_stats.log" 2>&1
 exit $?
 fi
 if [ "$1" != "--pmc-only" ]; then
 python3 "$ROOT/bench.py" > "$OUT/bench_full.json" 2> "$OUT/bench_full.err" || exit 1
 python3 "$ROOT/bench.py" --no-cpu-baseline > "$OUT/bench_unprofiled.json" 2> "$OUT/bench_unprofiled.err" || exit 1
-# --no-miopen-find: under the profiler MIOpen ignores the find-db hit and benchmarks every solver again (28 s of
-# naive_conv kernels in the trace); immediate mode picks the same tuned solvers from the db without a find
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_stats" -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-miopen-find > "$OUT/bench_stats.log" 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_stats" -- python3 "$ROOT/bench.py" --no-cpu-baseline > "$OUT/bench_stats.log" 2>&1 || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kbench_stats" -- python3 "$ROOT/tools/kbench.py" > "$OUT/kbench_stats.log" 2>&1 || exit 1
 fi
 # FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950 ("exceeds the capabilities of the hardware"): one each
