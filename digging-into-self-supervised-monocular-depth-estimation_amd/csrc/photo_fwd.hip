@@ -288,7 +288,8 @@ MDX_DEV void photometric_fwd_body(const FwdArgs &a)
 }
 
 template <int S, bool IDENT>
-__global__ __launch_bounds__(NT, 5) void photometric_fwd_kernel(FwdArgs a)
+// blocks per CU: 5 by registers for S <= 2; the warped tiles of more frames make LDS the limit (4, then 3)
+__global__ __launch_bounds__(NT, S <= 2 ? 5 : (S == 3 ? 4 : 3)) void photometric_fwd_kernel(FwdArgs a)
 {
     photometric_fwd_body<S, IDENT, false>(a);
 }
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(NT, 5) void photometric_fwd_kernel(FwdArgs a)
 // training form: exactly four waves per SIMD (128 VGPRs) -- the window statistics of every frame stay live until
 // the arg-min is known
 template <int S>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void photometric_fwd_coef_kernel(FwdArgs a)
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(S <= 3 ? 4 : 3, S <= 3 ? 4 : 3))) void photometric_fwd_coef_kernel(FwdArgs a)
 {
     photometric_fwd_body<S, false, true>(a);
 }
