@@ -1,0 +1,251 @@
+// glue.hip -- memory-bound glue of the depth / pose networks around MIOpen's convolutions, gfx950.
+//
+//   decoder glue   model_layer/depth_decoder.py:44-47,96-106 : ELU -> nearest x2 -> concat encoder skip ->
+//                  ReflectionPad2d(1), i.e. everything between two decoder convolutions, as ONE pass:
+//                      out[b, c, yo, xo] = c < C1 ? act(raw[b, c, y / u, x / u]) : skip[b, c - C1, y, x]
+//                      with (y, x) = reflect(yo - 1, xo - 1), u = 2 (upsample) or 1, act = ELU or identity.
+//                  The unfused sequence moves ~23 N + 4 S floats through HBM (N = |raw|, S = |skip|), this ~5 N + 2 S.
+//                  Backward is a gather (no atomics): each unpadded position sums the <= 2 x 2 padded positions that
+//                  reflect onto it; the raw gradient additionally folds the 2 x 2 upsample block and ELU'.
+//   max-pool 3x3 / stride 2 / pad 1   (ResNet stem, model_layer/depth_encoder.py): forward keeps the 0..8 window
+//                  index of the first maximum (ATen's strict-> scan), backward gathers from the <= 4 windows that
+//                  contain an input position.
+// float32 and bfloat16 (networks under autocast) storage, arithmetic in float32.  Thread <-> x: rows coalesce.
+#include "mdx_common.hpp"
+#include <stdint.h>
+
+namespace mdx {
+
+struct bf16 { uint16_t v; };
+
+__device__ __forceinline__ float to_float(float x) { return x; }
+__device__ __forceinline__ float to_float(bf16 x) { return __uint_as_float((uint32_t)x.v << 16); }
+template <typename T> __device__ __forceinline__ T from_float(float x);
+template <> __device__ __forceinline__ float from_float<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16 from_float<bf16>(float x)
+{
+    // round to nearest even, NaN stays NaN (torch's float -> bfloat16)
+    uint32_t u = __float_as_uint(x);
+    bf16 r;
+    if ((u & 0x7fffffffu) > 0x7f800000u) { r.v = (uint16_t)((u >> 16) | 0x40u); return r; }
+    u += 0x7fffu + ((u >> 16) & 1u);
+    r.v = (uint16_t)(u >> 16);
+    return r;
+}
+
+__device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }
+
+constexpr int GX = 64, GY = 4;   // block = 64 x 4 threads: a wave per output row segment
+
+// ---- decoder glue, forward.  grid: (ceil(Wp/64), ceil(Hp/4), B*(C1+C2)) ----
+template <typename TI, typename TO>
+__global__ __launch_bounds__(GX *GY) void decoder_glue_fwd_kernel(const TI *__restrict__ raw, const TI *__restrict__ skip,
+                                                                   TO *__restrict__ out, int C1, int C2, int h, int w,
+                                                                   int up, int elu)
+{
+    const int u = up ? 2 : 1;
+    const int H = h * u, W = w * u, Hp = H + 2, Wp = W + 2;
+    const int xo = blockIdx.x * GX + threadIdx.x, yo = blockIdx.y * GY + threadIdx.y;
+    if (xo >= Wp || yo >= Hp) return;
+    const int bc = blockIdx.z, C = C1 + C2, b = bc / C, c = bc - b * C;
+    const int y = reflect1(yo - 1, H), x = reflect1(xo - 1, W);
+    float v;
+    if (c < C1) {
+        v = to_float(raw[(((size_t)b * C1 + c) * h + y / u) * w + x / u]);
+        if (elu) v = elu1(v);
+    } else {
+        v = to_float(skip[(((size_t)b * C2 + (c - C1)) * H + y) * W + x]);
+    }
+    out[((size_t)bc * Hp + yo) * Wp + xo] = from_float<TO>(v);
+}
+
+// sum of the padded-gradient positions that reflect onto unpadded (y, x); gp = plane [Hp][Wp]
+template <typename T> __device__ __forceinline__ float fold_pad(const T *__restrict__ gp, int y, int x, int H, int W)
+{
+    const int Wp = W + 2;
+    const int ys[3] = {y + 1, y == 1 ? 0 : -1, y == H - 2 ? H + 1 : -1};
+    const int xs[3] = {x + 1, x == 1 ? 0 : -1, x == W - 2 ? W + 1 : -1};
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        if (ys[i] < 0) continue;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (xs[j] >= 0) acc += to_float(gp[(size_t)ys[i] * Wp + xs[j]]);
+    }
+    return acc;
+}
+
+// ---- decoder glue, backward w.r.t. raw.  grid: (ceil(w/64), ceil(h/4), B*C1) ----
+template <typename TI, typename TO>
+__global__ __launch_bounds__(GX *GY) void decoder_glue_bwd_raw_kernel(const TO *__restrict__ gout, const TI *__restrict__ raw,
+                                                                       TI *__restrict__ graw, int C1, int C2, int h, int w,
+                                                                       int up, int elu)
+{
+    const int u = up ? 2 : 1;
+    const int H = h * u, W = w * u;
+    const int xx = blockIdx.x * GX + threadIdx.x, yy = blockIdx.y * GY + threadIdx.y;
+    if (xx >= w || yy >= h) return;
+    const int bc = blockIdx.z, b = bc / C1, c = bc - b * C1;
+    const TO *gp = gout + ((size_t)b * (C1 + C2) + c) * (size_t)(H + 2) * (W + 2);
+    float g = 0.f;
+    for (int dy = 0; dy < u; ++dy)
+        for (int dx = 0; dx < u; ++dx) g += fold_pad(gp, u * yy + dy, u * xx + dx, H, W);
+    const size_t i = ((size_t)bc * h + yy) * w + xx;
+    if (elu) {
+        const float r = to_float(raw[i]);
+        g = r > 0.f ? g : g * __expf(r);
+    }
+    graw[i] = from_float<TI>(g);
+}
+
+// ---- decoder glue, backward w.r.t. skip.  grid: (ceil(W/64), ceil(H/4), B*C2) ----
+template <typename TI, typename TO>
+__global__ __launch_bounds__(GX *GY) void decoder_glue_bwd_skip_kernel(const TO *__restrict__ gout, TI *__restrict__ gskip,
+                                                                        int C1, int C2, int H, int W)
+{
+    const int x = blockIdx.x * GX + threadIdx.x, y = blockIdx.y * GY + threadIdx.y;
+    if (x >= W || y >= H) return;
+    const int bc = blockIdx.z, b = bc / C2, c = bc - b * C2;
+    const TO *gp = gout + ((size_t)b * (C1 + C2) + C1 + c) * (size_t)(H + 2) * (W + 2);
+    gskip[((size_t)bc * H + y) * W + x] = from_float<TI>(fold_pad(gp, y, x, H, W));
+}
+
+// ---- max-pool 3x3 / 2 / 1.  grid: (ceil(Wo/64), ceil(Ho/4), B*C) ----
+template <typename T>
+__global__ __launch_bounds__(GX *GY) void maxpool3s2_fwd_kernel(const T *__restrict__ in, T *__restrict__ out,
+                                                                 uint8_t *__restrict__ arg, int H, int W, int Ho, int Wo)
+{
+    const int xo = blockIdx.x * GX + threadIdx.x, yo = blockIdx.y * GY + threadIdx.y;
+    if (xo >= Wo || yo >= Ho) return;
+    const T *p = in + (size_t)blockIdx.z * H * W;
+    float best = -INFINITY;
+    int bi = -1;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int y = 2 * yo - 1 + k / 3, x = 2 * xo - 1 + k % 3;
+        if (y < 0 || y >= H || x < 0 || x >= W) continue;
+        const float v = to_float(p[(size_t)y * W + x]);
+        if (bi < 0) bi = k;                               // ATen starts from the first in-bounds tap
+        if (v > best || v != v) { best = v; bi = k; }     // strict >: the first maximum wins; NaN propagates
+    }
+    const size_t o = ((size_t)blockIdx.z * Ho + yo) * Wo + xo;
+    out[o] = from_float<T>(best);
+    arg[o] = (uint8_t)bi;
+}
+
+// grid: (ceil(W/64), ceil(H/4), B*C)
+template <typename T>
+__global__ __launch_bounds__(GX *GY) void maxpool3s2_bwd_kernel(const T *__restrict__ gout, const uint8_t *__restrict__ arg,
+                                                                 T *__restrict__ gin, int H, int W, int Ho, int Wo)
+{
+    const int x = blockIdx.x * GX + threadIdx.x, y = blockIdx.y * GY + threadIdx.y;
+    if (x >= W || y >= H) return;
+    const T *gp = gout + (size_t)blockIdx.z * Ho * Wo;
+    const uint8_t *ap = arg + (size_t)blockIdx.z * Ho * Wo;
+    float g = 0.f;
+    // windows (yo, xo) containing (y, x): 2*yo - 1 <= y <= 2*yo + 1
+    for (int yo = (y) / 2; yo <= (y + 1) / 2; ++yo) {
+        if (yo >= Ho) continue;
+        const int ky = y - (2 * yo - 1);
+        for (int xo = (x) / 2; xo <= (x + 1) / 2; ++xo) {
+            if (xo >= Wo) continue;
+            const int kx = x - (2 * xo - 1);
+            if (ap[(size_t)yo * Wo + xo] == ky * 3 + kx) g += to_float(gp[(size_t)yo * Wo + xo]);
+        }
+    }
+    gin[((size_t)blockIdx.z * H + y) * W + x] = from_float<T>(g);
+}
+
+static inline dim3 grid3(int nx, int ny, int nz) { return dim3((nx + GX - 1) / GX, (ny + GY - 1) / GY, nz); }
+
+}  // namespace mdx
+
+using namespace mdx;
+
+// dtype codes of the glue entry points
+enum { MDX_F32 = 0, MDX_BF16 = 1 };
+
+MDX_EXPORT int mdx_decoder_glue_fwd(const void *raw, const void *skip, void *out, int B, int C1, int C2, int h, int w,
+                                    int upsample, int elu, int in_dtype, int out_dtype, void *stream)
+{
+    if (!raw || !out || (C2 > 0 && !skip)) return MDX_ERR_NULL_POINTER;
+    const int u = upsample ? 2 : 1;
+    if (B <= 0 || C1 <= 0 || C2 < 0 || h <= 0 || w <= 0 || h * u < 2 || w * u < 2 || (long long)B * (C1 + C2) > 65535)
+        return MDX_ERR_BAD_SHAPE;
+    const dim3 grid = grid3(w * u + 2, h * u + 2, B * (C1 + C2)), block(GX, GY);
+    hipStream_t st = (hipStream_t)stream;
+    if (in_dtype == MDX_F32 && out_dtype == MDX_F32)
+        hipLaunchKernelGGL((decoder_glue_fwd_kernel<float, float>), grid, block, 0, st, (const float *)raw,
+                           (const float *)skip, (float *)out, C1, C2, h, w, upsample, elu);
+    else if (in_dtype == MDX_BF16 && out_dtype == MDX_BF16)
+        hipLaunchKernelGGL((decoder_glue_fwd_kernel<bf16, bf16>), grid, block, 0, st, (const bf16 *)raw,
+                           (const bf16 *)skip, (bf16 *)out, C1, C2, h, w, upsample, elu);
+    else if (in_dtype == MDX_BF16 && out_dtype == MDX_F32)
+        hipLaunchKernelGGL((decoder_glue_fwd_kernel<bf16, float>), grid, block, 0, st, (const bf16 *)raw,
+                           (const bf16 *)skip, (float *)out, C1, C2, h, w, upsample, elu);
+    else
+        return MDX_ERR_BAD_SHAPE;
+    return check_launch();
+}
+
+MDX_EXPORT int mdx_decoder_glue_bwd(const void *gout, const void *raw, void *graw, void *gskip, int B, int C1, int C2,
+                                    int h, int w, int upsample, int elu, int in_dtype, int out_dtype, void *stream)
+{
+    if (!gout || !raw || !graw || (C2 > 0 && !gskip)) return MDX_ERR_NULL_POINTER;
+    const int u = upsample ? 2 : 1;
+    if (B <= 0 || C1 <= 0 || C2 < 0 || h <= 0 || w <= 0 || h * u < 2 || w * u < 2 || (long long)B * (C1 + C2) > 65535)
+        return MDX_ERR_BAD_SHAPE;
+    const dim3 block(GX, GY), graw_grid = grid3(w, h, B * C1), gskip_grid = grid3(w * u, h * u, B * (C2 > 0 ? C2 : 1));
+    hipStream_t st = (hipStream_t)stream;
+#define MDX_GLUE_BWD(TI, TO)                                                                                          \
+    do {                                                                                                              \
+        hipLaunchKernelGGL((decoder_glue_bwd_raw_kernel<TI, TO>), graw_grid, block, 0, st, (const TO *)gout,          \
+                           (const TI *)raw, (TI *)graw, C1, C2, h, w, upsample, elu);                                  \
+        if (C2 > 0)                                                                                                   \
+            hipLaunchKernelGGL((decoder_glue_bwd_skip_kernel<TI, TO>), gskip_grid, block, 0, st, (const TO *)gout,    \
+                               (TI *)gskip, C1, C2, h * u, w * u);                                                     \
+    } while (0)
+    if (in_dtype == MDX_F32 && out_dtype == MDX_F32) MDX_GLUE_BWD(float, float);
+    else if (in_dtype == MDX_BF16 && out_dtype == MDX_BF16) MDX_GLUE_BWD(bf16, bf16);
+    else if (in_dtype == MDX_BF16 && out_dtype == MDX_F32) MDX_GLUE_BWD(bf16, float);
+    else return MDX_ERR_BAD_SHAPE;
+#undef MDX_GLUE_BWD
+    return check_launch();
+}
+
+MDX_EXPORT int mdx_maxpool3s2_fwd(const void *in, void *out, uint8_t *arg, int BC, int H, int W, int dtype, void *stream)
+{
+    if (!in || !out || !arg) return MDX_ERR_NULL_POINTER;
+    if (BC <= 0 || BC > 65535 || H <= 0 || W <= 0) return MDX_ERR_BAD_SHAPE;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;   // floor((H + 2 - 3) / 2) + 1
+    const dim3 grid = grid3(Wo, Ho, BC), block(GX, GY);
+    if (dtype == MDX_F32)
+        hipLaunchKernelGGL((maxpool3s2_fwd_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float *)in,
+                           (float *)out, arg, H, W, Ho, Wo);
+    else if (dtype == MDX_BF16)
+        hipLaunchKernelGGL((maxpool3s2_fwd_kernel<bf16>), grid, block, 0, (hipStream_t)stream, (const bf16 *)in,
+                           (bf16 *)out, arg, H, W, Ho, Wo);
+    else
+        return MDX_ERR_BAD_SHAPE;
+    return check_launch();
+}
+
+MDX_EXPORT int mdx_maxpool3s2_bwd(const void *gout, const uint8_t *arg, void *gin, int BC, int H, int W, int dtype,
+                                  void *stream)
+{
+    if (!gout || !arg || !gin) return MDX_ERR_NULL_POINTER;
+    if (BC <= 0 || BC > 65535 || H <= 0 || W <= 0) return MDX_ERR_BAD_SHAPE;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const dim3 grid = grid3(W, H, BC), block(GX, GY);
+    if (dtype == MDX_F32)
+        hipLaunchKernelGGL((maxpool3s2_bwd_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float *)gout, arg,
+                           (float *)gin, H, W, Ho, Wo);
+    else if (dtype == MDX_BF16)
+        hipLaunchKernelGGL((maxpool3s2_bwd_kernel<bf16>), grid, block, 0, (hipStream_t)stream, (const bf16 *)gout, arg,
+                           (bf16 *)gin, H, W, Ho, Wo);
+    else
+        return MDX_ERR_BAD_SHAPE;
+    return check_launch();
+}

@@ -48,6 +48,8 @@ SYMBOLS = {
     "mdx_min_automask_fwd": C.c_int,
     "mdx_event_create": C.c_void_p, "mdx_event_destroy": None, "mdx_event_elapsed_us": C.c_int,
     "mdx_photometric_fwd_timed": C.c_int, "mdx_photometric_bwd_timed": C.c_int,
+    "mdx_decoder_glue_fwd": C.c_int, "mdx_decoder_glue_bwd": C.c_int,
+    "mdx_maxpool3s2_fwd": C.c_int, "mdx_maxpool3s2_bwd": C.c_int,
 }
 
 

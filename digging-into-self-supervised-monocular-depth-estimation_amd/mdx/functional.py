@@ -410,3 +410,96 @@ def min_automask(ident, noise, reproj, automask=True, need_combined=False):
                                      int(automask), ptr(comb, optional=True), ptr(to_opt), ptr(idx, torch.uint8),
                                      stream()), "mdx_min_automask_fwd")
     return to_opt, idx, comb
+
+
+# ---- network glue around the convolutions (csrc/glue.hip) ---------------------------------------------------------
+_DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1}
+
+
+def _glue_dtype(t, what):
+    if not t.is_cuda:
+        raise _lib.MdxError("%s needs CUDA tensors (the HIP path has no CPU fallback), got %s" % (what, t.device))
+    if t.dtype not in _DTYPE_CODE:
+        raise _lib.MdxError("%s supports float32 / bfloat16, got %s" % (what, t.dtype))
+    return _DTYPE_CODE[t.dtype]
+
+
+class _DecoderGlue(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, raw, skip, elu, upsample, out_dtype):
+        raw = raw.contiguous()
+        in_code = _glue_dtype(raw, "decoder_glue")
+        B, C1, h, w = raw.shape
+        u = 2 if upsample else 1
+        C2 = 0
+        if skip is not None:
+            skip = skip.contiguous()
+            if skip.dtype != raw.dtype or skip.shape[0] != B or tuple(skip.shape[2:]) != (u * h, u * w):
+                raise _lib.MdxError("decoder_glue: skip %s %s does not match raw %s %s (x%d)"
+                                    % (tuple(skip.shape), skip.dtype, tuple(raw.shape), raw.dtype, u))
+            C2 = skip.shape[1]
+        out = torch.empty(B, C1 + C2, u * h + 2, u * w + 2, device=raw.device, dtype=out_dtype)
+        check(lib().mdx_decoder_glue_fwd(ptr(raw, raw.dtype), ptr(skip, raw.dtype) if skip is not None else None,
+                                         ptr(out, out_dtype), B, C1, C2, h, w, int(upsample), int(elu), in_code,
+                                         _DTYPE_CODE[out_dtype], stream()), "mdx_decoder_glue_fwd")
+        ctx.save_for_backward(raw)
+        ctx.meta = (C2, bool(elu), bool(upsample), out_dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (raw,) = ctx.saved_tensors
+        C2, elu, upsample, out_dtype = ctx.meta
+        B, C1, h, w = raw.shape
+        u = 2 if upsample else 1
+        gout = gout.contiguous().to(out_dtype)
+        graw = torch.empty_like(raw)
+        gskip = torch.empty(B, C2, u * h, u * w, device=raw.device, dtype=raw.dtype) if C2 else None
+        check(lib().mdx_decoder_glue_bwd(ptr(gout, out_dtype), ptr(raw, raw.dtype), ptr(graw, raw.dtype),
+                                         ptr(gskip, raw.dtype) if C2 else None, B, C1, C2, h, w, int(upsample),
+                                         int(elu), _DTYPE_CODE[raw.dtype], _DTYPE_CODE[out_dtype], stream()),
+              "mdx_decoder_glue_bwd")
+        return graw, gskip, None, None, None
+
+
+def decoder_glue(raw, skip=None, elu=True, upsample=True, out_dtype=None):
+    """ReflectionPad2d(1)(cat(nearest_x2(ELU(raw)), skip)) in one pass (reference: depth_decoder.py:44-47,96-106).
+
+    raw [B,C1,h,w] (the convolution output BEFORE its ELU), skip [B,C2,u*h,u*w] or None -> [B,C1+C2,u*h+2,u*w+2].
+    elu / upsample switch the two stages off (plain pad: elu=False, upsample=False).  float32 or bfloat16."""
+    out_dtype = out_dtype or raw.dtype
+    if skip is not None and skip.dtype != raw.dtype:
+        skip = skip.to(raw.dtype)
+    return _DecoderGlue.apply(raw, skip, bool(elu), bool(upsample), out_dtype)
+
+
+class _MaxPool3s2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        code = _glue_dtype(x, "maxpool3s2")
+        B, Cc, H, W = x.shape
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        out = torch.empty(B, Cc, Ho, Wo, device=x.device, dtype=x.dtype)
+        arg = torch.empty(B, Cc, Ho, Wo, device=x.device, dtype=torch.uint8)
+        check(lib().mdx_maxpool3s2_fwd(ptr(x, x.dtype), ptr(out, x.dtype), ptr(arg, torch.uint8), B * Cc, H, W, code,
+                                       stream()), "mdx_maxpool3s2_fwd")
+        ctx.save_for_backward(arg)
+        ctx.meta = (H, W, x.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (arg,) = ctx.saved_tensors
+        H, W, dtype = ctx.meta
+        B, Cc = arg.shape[:2]
+        gout = gout.contiguous().to(dtype)
+        gin = torch.empty(B, Cc, H, W, device=gout.device, dtype=dtype)
+        check(lib().mdx_maxpool3s2_bwd(ptr(gout, dtype), ptr(arg, torch.uint8), ptr(gin, dtype), B * Cc, H, W,
+                                       _DTYPE_CODE[dtype], stream()), "mdx_maxpool3s2_bwd")
+        return gin
+
+
+def maxpool3s2(x):
+    """MaxPool2d(kernel_size=3, stride=2, padding=1) (ResNet stem); backward is a gather, not ATen's atomics."""
+    return _MaxPool3s2.apply(x)

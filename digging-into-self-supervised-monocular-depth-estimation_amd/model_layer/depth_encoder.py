@@ -139,7 +139,13 @@ class ResnetEncoder(nn.Module):
         x = self.encoder.conv1(x)
         x = self.encoder.bn1(x)
         self.features.append(self.encoder.relu(x))
-        self.features.append(self.encoder.layer1(self.encoder.maxpool(self.features[-1])))
+        stem = self.features[-1]
+        if stem.is_cuda and stem.dtype in (torch.float32, torch.bfloat16):
+            from mdx import functional as F      # gather-based backward instead of ATen's atomics (csrc/glue.hip)
+            pooled = F.maxpool3s2(stem)
+        else:
+            pooled = self.encoder.maxpool(stem)
+        self.features.append(self.encoder.layer1(pooled))
         self.features.append(self.encoder.layer2(self.features[-1]))
         self.features.append(self.encoder.layer3(self.features[-1]))
         self.features.append(self.encoder.layer4(self.features[-1]))

@@ -245,3 +245,4 @@ def test_abi_reports_misuse_on_gpu(G):
     out = torch.empty(1, 1, 32, 64, device=G.DEV)
     rc = _lib.lib().mdx_identity_loss(C.byref(d), C.c_void_p(mis.data_ptr()), C.byref(src), _lib.ptr(out), _lib.stream())
     assert rc == -6   # MDX_ERR_MISALIGNED
+
