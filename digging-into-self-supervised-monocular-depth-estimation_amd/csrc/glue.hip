@@ -135,27 +135,46 @@ __global__ __launch_bounds__(GX *GY) void maxpool3s2_fwd_kernel(const T *__restr
     arg[o] = (uint8_t)bi;
 }
 
-// grid: (ceil(W/64), ceil(H/4), B*C)
+// One thread per 2x2 input block (rows 2*yo, 2*yo+1; columns 2*xo, 2*xo+1): only the four windows (yo..yo+1,
+// xo..xo+1) can have selected one of its pixels, so four index bytes and four gradients serve four outputs.
+// grid: (ceil(ceil(W/2)/64), ceil(ceil(H/2)/4), B*C)
 template <typename T>
 __global__ __launch_bounds__(GX *GY) void maxpool3s2_bwd_kernel(const T *__restrict__ gout, const uint8_t *__restrict__ arg,
                                                                  T *__restrict__ gin, int H, int W, int Ho, int Wo)
 {
-    const int x = blockIdx.x * GX + threadIdx.x, y = blockIdx.y * GY + threadIdx.y;
-    if (x >= W || y >= H) return;
+    const int xo = blockIdx.x * GX + threadIdx.x, yo = blockIdx.y * GY + threadIdx.y;
+    if (2 * xo >= W || 2 * yo >= H) return;
     const T *gp = gout + (size_t)blockIdx.z * Ho * Wo;
     const uint8_t *ap = arg + (size_t)blockIdx.z * Ho * Wo;
-    float g = 0.f;
-    // windows (yo, xo) containing (y, x): 2*yo - 1 <= y <= 2*yo + 1
-    for (int yo = (y) / 2; yo <= (y + 1) / 2; ++yo) {
-        if (yo >= Ho) continue;
-        const int ky = y - (2 * yo - 1);
-        for (int xo = (x) / 2; xo <= (x + 1) / 2; ++xo) {
-            if (xo >= Wo) continue;
-            const int kx = x - (2 * xo - 1);
-            if (ap[(size_t)yo * Wo + xo] == ky * 3 + kx) g += to_float(gp[(size_t)yo * Wo + xo]);
+    float gw[2][2];
+    int aw[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const bool in = (yo + j < Ho) && (xo + i < Wo);
+            const size_t o = (size_t)(in ? yo + j : yo) * Wo + (in ? xo + i : xo);
+            aw[j][i] = in ? (int)ap[o] : -1;
+            gw[j][i] = to_float(gp[o]);
+        }
+    T *op = gin + (size_t)blockIdx.z * H * W;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int y = 2 * yo + a;
+        if (y >= H) break;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int x = 2 * xo + b;
+            if (x >= W) break;
+            // pixel (a, b) of the block is tap (a+1, b+1) of window (yo, xo), tap (a+1, 0) of (yo, xo+1) when b == 1,
+            // tap (0, b+1) of (yo+1, xo) when a == 1 and tap (0, 0) of (yo+1, xo+1) when a == b == 1
+            float g = aw[0][0] == (a + 1) * 3 + (b + 1) ? gw[0][0] : 0.f;
+            if (b == 1 && aw[0][1] == (a + 1) * 3) g += gw[0][1];
+            if (a == 1 && aw[1][0] == (b + 1)) g += gw[1][0];
+            if (a == 1 && b == 1 && aw[1][1] == 0) g += gw[1][1];
+            op[(size_t)y * W + x] = from_float<T>(g);
         }
     }
-    gin[((size_t)blockIdx.z * H + y) * W + x] = from_float<T>(g);
 }
 
 static inline dim3 grid3(int nx, int ny, int nz) { return dim3((nx + GX - 1) / GX, (ny + GY - 1) / GY, nz); }
@@ -238,7 +257,7 @@ MDX_EXPORT int mdx_maxpool3s2_bwd(const void *gout, const uint8_t *arg, void *gi
     if (!gout || !arg || !gin) return MDX_ERR_NULL_POINTER;
     if (BC <= 0 || BC > 65535 || H <= 0 || W <= 0) return MDX_ERR_BAD_SHAPE;
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-    const dim3 grid = grid3(W, H, BC), block(GX, GY);
+    const dim3 grid = grid3((W + 1) / 2, (H + 1) / 2, BC), block(GX, GY);
     if (dtype == MDX_F32)
         hipLaunchKernelGGL((maxpool3s2_bwd_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float *)gout, arg,
                            (float *)gin, H, W, Ho, Wo);

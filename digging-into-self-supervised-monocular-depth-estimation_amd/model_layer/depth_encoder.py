@@ -10,7 +10,42 @@ import warnings
 import numpy as np
 import torch
 import torch.nn as nn
+import torch.nn.functional as TF
 
+
+
+class BatchNorm2d(nn.BatchNorm2d):
+    """nn.BatchNorm2d whose `num_batches_tracked` counter lives on the host while training.
+
+    The stock module launches one tiny add kernel per layer and step for that counter (60 launches per training
+    step of this path), and with a fixed momentum nothing ever reads it.  Same parameters, buffers and state-dict
+    keys; the buffer is brought up to date whenever the state dict is taken.  momentum=None (cumulative average,
+    which does read the counter) keeps the stock behaviour."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._pending_batches = 0
+
+    def forward(self, x):
+        if self.momentum is None or not self.track_running_stats:
+            return super().forward(x)
+        if self.training:
+            self._pending_batches += 1
+        return TF.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, self.training,
+                             self.momentum, self.eps)
+
+    def _flush_counter(self):
+        if self._pending_batches and self.num_batches_tracked is not None:
+            self.num_batches_tracked += self._pending_batches
+        self._pending_batches = 0
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        self._flush_counter()
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._pending_batches = 0
+        super()._load_from_state_dict(*args, **kwargs)
 
 class BasicBlock(nn.Module):
     expansion = 1
@@ -18,10 +53,10 @@ class BasicBlock(nn.Module):
     def __init__(self, inplanes, planes, stride=1, downsample=None):
         super().__init__()
         self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
-        self.bn1 = nn.BatchNorm2d(planes)
+        self.bn1 = BatchNorm2d(planes)
         self.relu = nn.ReLU(inplace=True)
         self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
-        self.bn2 = nn.BatchNorm2d(planes)
+        self.bn2 = BatchNorm2d(planes)
         self.downsample = downsample
 
     def forward(self, x):
@@ -37,11 +72,11 @@ class Bottleneck(nn.Module):
     def __init__(self, inplanes, planes, stride=1, downsample=None):
         super().__init__()
         self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
-        self.bn1 = nn.BatchNorm2d(planes)
+        self.bn1 = BatchNorm2d(planes)
         self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)
-        self.bn2 = nn.BatchNorm2d(planes)
+        self.bn2 = BatchNorm2d(planes)
         self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
-        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.bn3 = BatchNorm2d(planes * 4)
         self.relu = nn.ReLU(inplace=True)
         self.downsample = downsample
 
@@ -64,7 +99,7 @@ class ResNet(nn.Module):
         super().__init__()
         self.inplanes = 64
         self.conv1 = nn.Conv2d(num_input_images * 3, 64, kernel_size=7, stride=2, padding=3, bias=False)
-        self.bn1 = nn.BatchNorm2d(64)
+        self.bn1 = BatchNorm2d(64)
         self.relu = nn.ReLU(inplace=True)
         self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
         self.layer1 = self._make_layer(block, 64, layers[0])
@@ -85,7 +120,7 @@ class ResNet(nn.Module):
         if stride != 1 or self.inplanes != planes * block.expansion:
             downsample = nn.Sequential(
                 nn.Conv2d(self.inplanes, planes * block.expansion, 1, stride, bias=False),
-                nn.BatchNorm2d(planes * block.expansion))
+                BatchNorm2d(planes * block.expansion))
         layers = [block(self.inplanes, planes, stride, downsample)]
         self.inplanes = planes * block.expansion
         layers += [block(self.inplanes, planes) for _ in range(1, blocks)]

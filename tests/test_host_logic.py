@@ -154,3 +154,24 @@ def test_miopen_find_db_install(tmp_path, monkeypatch):
     monkeypatch.delenv("MIOPEN_USER_DB_PATH")
     monkeypatch.setenv("MDX_MIOPEN_DB", "0")
     assert tuning.install_miopen_db(rank=0) is None and "MIOPEN_USER_DB_PATH" not in os.environ
+
+
+def test_batchnorm_host_counter_keeps_state_dict_contract():
+    """model_layer.depth_encoder.BatchNorm2d: same numbers and state-dict keys as nn.BatchNorm2d; the
+    num_batches_tracked buffer is current whenever the state dict is taken."""
+    from model_layer.depth_encoder import BatchNorm2d
+    torch.manual_seed(0)
+    a, b = BatchNorm2d(5), torch.nn.BatchNorm2d(5)
+    b.load_state_dict(a.state_dict())
+    for _ in range(3):
+        x = torch.randn(4, 5, 6, 7)
+        torch.testing.assert_close(a(x), b(x))
+    sa, sb = a.state_dict(), b.state_dict()
+    assert list(sa) == list(sb)
+    for k in sa:
+        torch.testing.assert_close(sa[k], sb[k])
+    assert int(sa["num_batches_tracked"]) == 3
+    a.eval(), b.eval()
+    x = torch.randn(2, 5, 3, 3)
+    torch.testing.assert_close(a(x), b(x))
+    assert int(a.state_dict()["num_batches_tracked"]) == 3
