@@ -34,9 +34,11 @@ template <> __device__ __forceinline__ bf16 from_float<bf16>(float x)
 }
 
 __device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
-__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }
+__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : __expf(x) - 1.0f; }   // ATen: exp(x) - 1
 
 constexpr int GX = 64, GY = 4;   // block = 64 x 4 threads: a wave per output row segment
+constexpr int RPT = 4;           // rows per thread (GY apart): four independent loads in flight per lane --
+                                 // with one 4-byte access per thread a CU cannot keep enough bytes in flight
 
 // ---- decoder glue, forward.  grid: (ceil(Wp/64), ceil(Hp/4), B*(C1+C2)) ----
 template <typename TI, typename TO>
@@ -46,18 +48,24 @@ __global__ __launch_bounds__(GX *GY) void decoder_glue_fwd_kernel(const TI *__re
 {
     const int u = up ? 2 : 1;
     const int H = h * u, W = w * u, Hp = H + 2, Wp = W + 2;
-    const int xo = blockIdx.x * GX + threadIdx.x, yo = blockIdx.y * GY + threadIdx.y;
-    if (xo >= Wp || yo >= Hp) return;
+    const int xo = blockIdx.x * GX + threadIdx.x, y0 = blockIdx.y * (GY * RPT) + threadIdx.y;
+    if (xo >= Wp) return;
     const int bc = blockIdx.z, C = C1 + C2, b = bc / C, c = bc - b * C;
-    const int y = reflect1(yo - 1, H), x = reflect1(xo - 1, W);
-    float v;
-    if (c < C1) {
-        v = to_float(raw[(((size_t)b * C1 + c) * h + y / u) * w + x / u]);
-        if (elu) v = elu1(v);
-    } else {
-        v = to_float(skip[(((size_t)b * C2 + (c - C1)) * H + y) * W + x]);
+    const int x = reflect1(xo - 1, W);
+    float v[RPT];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        const int yo = y0 + r * GY;
+        const int y = reflect1((yo < Hp ? yo : 0) - 1, H);
+        v[r] = c < C1 ? to_float(raw[(((size_t)b * C1 + c) * h + y / u) * w + x / u])
+                      : to_float(skip[(((size_t)b * C2 + (c - C1)) * H + y) * W + x]);
     }
-    out[((size_t)bc * Hp + yo) * Wp + xo] = from_float<TO>(v);
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        const int yo = y0 + r * GY;
+        if (yo >= Hp) break;
+        out[((size_t)bc * Hp + yo) * Wp + xo] = from_float<TO>((c < C1 && elu) ? elu1(v[r]) : v[r]);
+    }
 }
 
 // sum of the padded-gradient positions that reflect onto unpadded (y, x); gp = plane [Hp][Wp]
@@ -85,19 +93,25 @@ __global__ __launch_bounds__(GX *GY) void decoder_glue_bwd_raw_kernel(const TO *
 {
     const int u = up ? 2 : 1;
     const int H = h * u, W = w * u;
-    const int xx = blockIdx.x * GX + threadIdx.x, yy = blockIdx.y * GY + threadIdx.y;
-    if (xx >= w || yy >= h) return;
+    const int xx = blockIdx.x * GX + threadIdx.x, y0 = blockIdx.y * (GY * RPT) + threadIdx.y;
+    if (xx >= w) return;
     const int bc = blockIdx.z, b = bc / C1, c = bc - b * C1;
     const TO *gp = gout + ((size_t)b * (C1 + C2) + c) * (size_t)(H + 2) * (W + 2);
-    float g = 0.f;
-    for (int dy = 0; dy < u; ++dy)
-        for (int dx = 0; dx < u; ++dx) g += fold_pad(gp, u * yy + dy, u * xx + dx, H, W);
-    const size_t i = ((size_t)bc * h + yy) * w + xx;
-    if (elu) {
-        const float r = to_float(raw[i]);
-        g = r > 0.f ? g : g * __expf(r);
+    float g[RPT], rv[RPT];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        const int yy = (y0 + r * GY < h) ? y0 + r * GY : 0;
+        g[r] = 0.f;
+        for (int dy = 0; dy < u; ++dy)
+            for (int dx = 0; dx < u; ++dx) g[r] += fold_pad(gp, u * yy + dy, u * xx + dx, H, W);
+        rv[r] = elu ? to_float(raw[((size_t)bc * h + yy) * w + xx]) : 1.f;
     }
-    graw[i] = from_float<TI>(g);
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        const int yy = y0 + r * GY;
+        if (yy >= h) break;
+        graw[((size_t)bc * h + yy) * w + xx] = from_float<TI>((elu && !(rv[r] > 0.f)) ? g[r] * __expf(rv[r]) : g[r]);
+    }
 }
 
 // ---- decoder glue, backward w.r.t. skip.  grid: (ceil(W/64), ceil(H/4), B*C2) ----
@@ -105,11 +119,19 @@ template <typename TI, typename TO>
 __global__ __launch_bounds__(GX *GY) void decoder_glue_bwd_skip_kernel(const TO *__restrict__ gout, TI *__restrict__ gskip,
                                                                         int C1, int C2, int H, int W)
 {
-    const int x = blockIdx.x * GX + threadIdx.x, y = blockIdx.y * GY + threadIdx.y;
-    if (x >= W || y >= H) return;
+    const int x = blockIdx.x * GX + threadIdx.x, y0 = blockIdx.y * (GY * RPT) + threadIdx.y;
+    if (x >= W) return;
     const int bc = blockIdx.z, b = bc / C2, c = bc - b * C2;
     const TO *gp = gout + ((size_t)b * (C1 + C2) + C1 + c) * (size_t)(H + 2) * (W + 2);
-    gskip[((size_t)bc * H + y) * W + x] = from_float<TI>(fold_pad(gp, y, x, H, W));
+    float g[RPT];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) g[r] = fold_pad(gp, (y0 + r * GY < H) ? y0 + r * GY : 0, x, H, W);
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        const int y = y0 + r * GY;
+        if (y >= H) break;
+        gskip[((size_t)bc * H + y) * W + x] = from_float<TI>(g[r]);
+    }
 }
 
 // ---- max-pool 3x3 / 2 / 1.  grid: (ceil(Wo/64), ceil(Ho/4), B*C) ----
@@ -178,6 +200,7 @@ __global__ __launch_bounds__(GX *GY) void maxpool3s2_bwd_kernel(const T *__restr
 }
 
 static inline dim3 grid3(int nx, int ny, int nz) { return dim3((nx + GX - 1) / GX, (ny + GY - 1) / GY, nz); }
+static inline dim3 grid3r(int nx, int ny, int nz) { return dim3((nx + GX - 1) / GX, (ny + GY * RPT - 1) / (GY * RPT), nz); }
 
 }  // namespace mdx
 
@@ -193,7 +216,7 @@ MDX_EXPORT int mdx_decoder_glue_fwd(const void *raw, const void *skip, void *out
     const int u = upsample ? 2 : 1;
     if (B <= 0 || C1 <= 0 || C2 < 0 || h <= 0 || w <= 0 || h * u < 2 || w * u < 2 || (long long)B * (C1 + C2) > 65535)
         return MDX_ERR_BAD_SHAPE;
-    const dim3 grid = grid3(w * u + 2, h * u + 2, B * (C1 + C2)), block(GX, GY);
+    const dim3 grid = grid3r(w * u + 2, h * u + 2, B * (C1 + C2)), block(GX, GY);
     hipStream_t st = (hipStream_t)stream;
     if (in_dtype == MDX_F32 && out_dtype == MDX_F32)
         hipLaunchKernelGGL((decoder_glue_fwd_kernel<float, float>), grid, block, 0, st, (const float *)raw,
@@ -216,7 +239,7 @@ MDX_EXPORT int mdx_decoder_glue_bwd(const void *gout, const void *raw, void *gra
     const int u = upsample ? 2 : 1;
     if (B <= 0 || C1 <= 0 || C2 < 0 || h <= 0 || w <= 0 || h * u < 2 || w * u < 2 || (long long)B * (C1 + C2) > 65535)
         return MDX_ERR_BAD_SHAPE;
-    const dim3 block(GX, GY), graw_grid = grid3(w, h, B * C1), gskip_grid = grid3(w * u, h * u, B * (C2 > 0 ? C2 : 1));
+    const dim3 block(GX, GY), graw_grid = grid3r(w, h, B * C1), gskip_grid = grid3r(w * u, h * u, B * (C2 > 0 ? C2 : 1));
     hipStream_t st = (hipStream_t)stream;
 #define MDX_GLUE_BWD(TI, TO)                                                                                          \
     do {                                                                                                              \
