@@ -67,9 +67,13 @@ def test_fused_forward_vs_golden(G, case):
         G.assert_close(out["sum"].cpu().numpy()[0] / n, tgt.astype(np.float64).mean(), "mean s%d" % s, rel=1e-6)
 
 
-def test_fused_loss_and_grads_vs_golden(G, case):
-    """Whole loss of compute_loss (processor.py:166-217) + autograd, against the reference's."""
+@pytest.mark.parametrize("bwd_path", ["coef", "saved_warp", "rewarp"])
+def test_fused_loss_and_grads_vs_golden(G, case, bwd_path):
+    """Whole loss of compute_loss (processor.py:166-217) + autograd, against the reference's -- through each of
+    the three backward kernels (coefficient maps = what training runs; saved warped colours; full re-warp)."""
     c = case
+    keep = dict(coef=dict(save_coef=True, save_warp=False), saved_warp=dict(save_coef=False, save_warp=True),
+                rewarp=dict(save_coef=False, save_warp=False))[bwd_path]
     K = G.t(c["K"])
     Ts = {f: G.t(c.T(f)).requires_grad_(f != "s") for f in c.sources_ids}
     P = torch.stack([G.F.compose_projection(K, Ts[f]) for f in c.sources_ids])
@@ -83,7 +87,7 @@ def test_fused_loss_and_grads_vs_golden(G, case):
         disps.append(disp)
         noise = G.t(c["noise_s%d" % s]) if c.automask else None
         out = G.F.photometric_scale(disp, P, G.t(c.color(0)), srcs, G.t(c["inv_K"]), ident, noise,
-                                    automask=c.automask)
+                                    automask=c.automask, **keep)
         sm = G.F.smooth_loss(disp, G.t(c.color(0, s)))
         G.assert_close(sm, c["smooth_s%d" % s], "smooth s%d" % s)
         total = total + out["sum"][0] / n + 1e-3 * sm / (2 ** s)
@@ -206,8 +210,8 @@ def test_fused_vs_oracle_full_size(G, B, H, W, S, scale):
 
 
 def test_fused_without_automask_and_recompute_backward(G):
-    """use_automasking=False (reprojection channels only, processor.py:197-198) and the backward's re-warp path
-    (save_warp=False) against the oracle at 192x640."""
+    """use_automasking=False (reprojection channels only, processor.py:197-198) and all three backward paths --
+    coefficient maps (the default), saved warped colours, full re-warp -- against the oracle at 192x640."""
     from oracle import oracle as orc
     B, H, W, S = 1, 192, 640, 2
     colors, K, invK, Ts, rng = _synth(B, H, W, S, seed=99)
@@ -217,16 +221,17 @@ def test_fused_without_automask_and_recompute_backward(G):
     n = B * H * W
     gd, gP = orc.photometric_bwd(disp, colors[0], colors[1:], invK, P_ref, ref["idx"], 1.0 / n, automask=False)
     srcs = [G.t(x) for x in colors[1:]]
-    for save_warp in (True, False):
+    for save_coef, save_warp in ((True, False), (False, True), (False, False)):
+        tag = "save_coef=%s save_warp=%s" % (save_coef, save_warp)
         dt = G.t(disp).requires_grad_(True)
         Pt = G.t(P_ref).requires_grad_(True)
         out = G.F.photometric_scale(dt, Pt, G.t(colors[0]), srcs, G.t(invK), automask=False, need_to_opt=True,
-                                    save_warp=save_warp)
+                                    save_coef=save_coef, save_warp=save_warp)
         G.assert_bitexact(out["to_opt"], ref["to_opt"], "to_opt")
         assert (out["idx"].cpu().numpy() == ref["idx"]).all()
         (out["sum"][0] / n).backward()
-        G.assert_close(dt.grad, gd, "grad disp (save_warp=%s)" % save_warp)
-        G.assert_close(Pt.grad, gP, "grad P (save_warp=%s)" % save_warp)
+        G.assert_close(dt.grad, gd, "grad disp (%s)" % tag)
+        G.assert_close(Pt.grad, gP, "grad P (%s)" % tag)
 
 
 def test_abi_reports_misuse_on_gpu(G):
