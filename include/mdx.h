@@ -217,6 +217,21 @@ int mdx_decoder_glue_bwd(const void *gout, const void *raw, void *graw, void *gs
 int mdx_maxpool3s2_fwd(const void *in, void *out, uint8_t *arg, int BC, int H, int W, int dtype, void *stream);
 int mdx_maxpool3s2_bwd(const void *gout, const uint8_t *arg, void *gin, int BC, int H, int W, int dtype, void *stream);
 
+/* Training-mode BatchNorm2d + residual add + ReLU of the ResNet blocks (model_layer/depth_encoder.py; the reference
+ * gets them from torchvision): y = act(bn(x) [+ res]) with batch statistics over (B,H,W), running statistics updated
+ * in place as torch.nn.functional.batch_norm(training=True) does (run_mean/run_var may both be NULL).
+ * x, res, y, dy, dx, dres: [B,C,H,W] float32 (dtype 0) or bfloat16 (dtype 1); gamma, beta, statistics float32.
+ * save_mean / save_invstd [C] go from forward to backward.  Two launches each way (statistics pass, apply pass). */
+size_t mdx_bn_workspace_bytes(int B, int C, int H, int W);
+int mdx_bn_act_fwd(const void *x, const void *res, const float *gamma, const float *beta, float *run_mean,
+                   float *run_var, void *y, float *save_mean, float *save_invstd, int B, int C, int H, int W,
+                   float eps, float momentum, int relu, int dtype, void *workspace, size_t workspace_bytes,
+                   void *stream);
+/* dz = dy * (y > 0) when relu; dx, d(res) = dz (dres NULL when there was no residual), dgamma, dbeta [C]. */
+int mdx_bn_act_bwd(const void *dy, const void *y, const void *x, const float *gamma, const float *save_mean,
+                   const float *save_invstd, void *dx, void *dres, float *dgamma, float *dbeta, int B, int C, int H,
+                   int W, int relu, int dtype, void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -105,3 +105,94 @@ def test_decoder_glue_path_equals_module_path(amp):
     for a, b in zip(fg, feats2):
         scale = float(b.grad.abs().max()) + 1e-12
         assert float((a.float() - b.grad.float()).abs().max()) <= (5e-4 if not amp else 8e-2) * scale
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cfg", [(12, 64, 48, 160, True, True), (3, 7, 5, 9, False, True), (2, 16, 96, 320, False, True),
+                                 (4, 32, 6, 20, True, False), (2, 8, 3, 3, False, False), (1, 5, 130, 67, True, True)])
+def test_bn_act_matches_torch(F, cfg, dtype):
+    """bn_act == relu(batch_norm(x, training=True) + residual): output, running statistics, all four gradients,
+    against torch's CPU batch norm in float64 (MIOpen's GPU batch norm drops elements for H*W % 4 != 0 planes --
+    db off by O(1) on the (130, 67) case below -- so it cannot be the oracle here)."""
+    B, Cc, H, W, has_res, relu = cfg
+    g = torch.Generator().manual_seed(21)
+    x0 = (torch.randn(B, Cc, H, W, generator=g) * 1.7 + 0.4).to(dtype)
+    res0 = torch.randn(B, Cc, H, W, generator=g).to(dtype) if has_res else None
+    w0, b0 = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g)
+    rm0, rv0 = torch.randn(Cc, generator=g), torch.rand(Cc, generator=g) + 0.5
+    gy0 = torch.randn(B, Cc, H, W, generator=g).to(dtype)
+
+    def leaf(t, dev, dt):
+        return t.to(dev, dt).requires_grad_(True)
+    # float64 reference on the CPU (from the same, already rounded, inputs)
+    x2, w2, b2 = leaf(x0, "cpu", torch.float64), leaf(w0, "cpu", torch.float64), leaf(b0, "cpu", torch.float64)
+    res2 = leaf(res0, "cpu", torch.float64) if has_res else None
+    rm2, rv2 = rm0.double(), rv0.double()
+    pre = torch.nn.functional.batch_norm(x2, rm2, rv2, w2, b2, True, 0.1, 1e-5)
+    if has_res:
+        pre = pre + res2
+    ref = torch.relu(pre) if relu else pre
+    # a pre-activation within rounding of zero may fall on either side of the ReLU: give those elements no gradient
+    f32 = dtype == torch.float32
+    sure = (pre.detach().abs() > (1e-4 if f32 else 5e-2)).to(dtype) if relu else torch.ones_like(gy0)
+    gy0 = gy0 * sure
+    ref.backward(gy0.double())
+
+    x, w, b = leaf(x0, "cuda", dtype), leaf(w0, "cuda", torch.float32), leaf(b0, "cuda", torch.float32)
+    res = leaf(res0, "cuda", dtype) if has_res else None
+    rm, rv = rm0.cuda(), rv0.cuda()
+    y = F.bn_act(x, w, b, rm, rv, 1e-5, 0.1, residual=res, relu=relu)
+    assert y.dtype == dtype and y.shape == ref.shape
+    y.backward(gy0.cuda())
+
+    def close(a, bb, name, tol):
+        scale = float(bb.abs().max()) + 1e-12
+        err = float((a.detach().double().cpu() - bb.detach()).abs().max()) / scale
+        assert err <= tol, "%s: %g" % (name, err)
+    close(y, ref, "y", 1e-5 if f32 else 1e-2)
+    close(rm, rm2, "running_mean", 1e-5)
+    close(rv, rv2, "running_var", 1e-5)
+    close(x.grad, x2.grad, "dx", 1e-4 if f32 else 3e-2)
+    close(w.grad, w2.grad, "dgamma", 1e-4 if f32 else 3e-2)
+    close(b.grad, b2.grad, "dbeta", 1e-4 if f32 else 3e-2)
+    if has_res:
+        close(res.grad, res2.grad, "dres", 1e-5 if f32 else 1e-2)
+
+
+@pytest.mark.parametrize("layers", [18, 50])
+def test_encoder_fused_norm_path_equals_module_path(layers, monkeypatch):
+    """ResnetEncoder in training mode on the GPU (fused norm + max-pool kernels) == the same modules op by op."""
+    from model_layer import ResnetEncoder
+    from model_layer.depth_encoder import BatchNorm2d
+    torch.manual_seed(5)
+    monkeypatch.setattr(BatchNorm2d, "fused_min_elements", 0)      # every layer through the fused kernels
+    enc = ResnetEncoder(layers, False).cuda().train()
+    ref = ResnetEncoder(layers, False).cuda().train()
+    ref.load_state_dict(enc.state_dict())
+    # 128x256: every map's H*W is a multiple of 4 (MIOpen's batch norm, the reference here, is off for other planes)
+    img = torch.rand(4, 3, 128, 256, device="cuda")
+    feats = enc(img)
+    loss = sum(f.mean() for f in feats)
+    loss.backward()
+    plain = BatchNorm2d.act
+    try:
+        BatchNorm2d.act = lambda self, x, residual=None, relu=True: \
+            (lambda o: torch.relu(o) if relu else o)(self(x) if residual is None else self(x) + residual)
+        feats2 = ref(img)
+        sum(f.mean() for f in feats2).backward()
+    finally:
+        BatchNorm2d.act = plain
+    tol = 2e-4 if layers == 18 else 2e-3        # 50 layers of float32 rounding differences add up
+    for a, b in zip(feats, feats2):
+        torch.testing.assert_close(a, b, rtol=tol, atol=tol)
+    sa, sb = enc.state_dict(), ref.state_dict()
+    for k in sa:
+        torch.testing.assert_close(sa[k].float(), sb[k].float(), rtol=tol, atol=tol, msg=k)
+    for (n, p), (_, q) in zip(enc.named_parameters(), ref.named_parameters()):
+        if p.grad is None:
+            assert q.grad is None
+            continue
+        # weights in front of a batch norm get gradients that are small differences of large terms (and MIOpen's
+        # weight-gradient kernels sum with atomics): compare in the Frobenius norm, with an absolute floor
+        err, scale = float((p.grad - q.grad).norm()), float(q.grad.norm())
+        assert err <= (2e-2 if layers == 18 else 1e-1) * scale + 1e-5, "%s: err %.3g scale %.3g" % (n, err, scale)
