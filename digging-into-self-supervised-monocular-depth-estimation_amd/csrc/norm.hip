@@ -7,7 +7,7 @@
 // HBM traffic for an N-element map, and 4-8 launches of a few microseconds each for the small maps.  Here:
 //     forward   stats pass (read x)  +  apply pass (read x [, identity], write y)              = 3 N (4 N)
 //     backward  stats pass (read dy, y, x)  +  apply pass (read dy, y, x, write dx [, d_identity]) = 7 N (8 N)
-// two launches each way.  NCHW: channel c of image b is one contiguous plane of HW elements; a block owns a span of
+// two launches each way (one for small maps, see below).  NCHW: channel c of image b is one contiguous plane of HW elements; a block owns a span of
 // one plane (<= 8192 elements), reads it with 16-byte (float32) / 8-byte (bfloat16) loads, four per thread in flight.
 // Per-channel sums: float32 inside a block (<= 8192 terms), combined across blocks in float64 (E[x^2] - mean^2 is
 // formed in float64).  Statistics are those of torch.nn.functional.batch_norm: biased variance to normalise,
@@ -233,6 +233,147 @@ __global__ __launch_bounds__(NB) void bn_bwd_apply_kernel(const T *__restrict__ 
                   if (orr) st(orr, i, dz);)
 }
 
+// -----------------------------------------------------------------------------------------------------------
+// Small maps (B*H*W <= SMALL_MAX elements per channel, H*W % 4 == 0): ONE launch each way.  One 1024-thread block
+// owns a channel, keeps its <= 24 elements per thread in registers between the reduction and the apply step, so the
+// activations cross HBM once (forward: read x [, identity], write y; backward: read dy, y, x, write dx [, d_identity]).
+// -----------------------------------------------------------------------------------------------------------
+constexpr int SB = 1024;                     // threads per block
+constexpr int SV = 6;                        // 4-element vectors per thread
+constexpr int SMALL_MAX = SB * SV * VEC;     // 24576 elements per channel
+
+__device__ __forceinline__ float block_sum_1024(float v, float *lds)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < SB / 64; ++k) t += lds[k];
+    __syncthreads();
+    return t;
+}
+
+// element offset (inside the [B,C,H,W] tensor) of vector j of this thread, or -1 beyond the channel's data
+__device__ __forceinline__ long long small_offset(int j, int c, int C, int HW, int M)
+{
+    const int e = (j * SB + threadIdx.x) * VEC;       // linear index over (b, hw) of channel c
+    if (e >= M) return -1;
+    const int b = e / HW, off = e - b * HW;
+    return ((long long)b * C + c) * HW + off;
+}
+
+template <typename T>
+__global__ __launch_bounds__(SB) void bn_small_fwd_kernel(const T *__restrict__ x, const T *__restrict__ res,
+                                                          const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                          int C, int HW, int B, float eps, float momentum, int relu,
+                                                          T *__restrict__ y, float *__restrict__ save_mean,
+                                                          float *__restrict__ save_invstd, float *__restrict__ run_mean,
+                                                          float *__restrict__ run_var)
+{
+    __shared__ float lds[SB / 64];
+    const int c = blockIdx.x, M = B * HW;
+    long long o[SV];
+    Vec4<T> v[SV];
+    float a = 0.f;
+#pragma unroll
+    for (int j = 0; j < SV; ++j) {
+        o[j] = small_offset(j, c, C, HW, M);
+        if (o[j] >= 0) v[j] = *reinterpret_cast<const Vec4<T> *>(x + o[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < SV; ++j)
+        if (o[j] >= 0)
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) a += ld(v[j].v, k);
+    const float mean = block_sum_1024(a, lds) / (float)M;
+    float q = 0.f;                                   // two-pass variance: the data is in registers
+#pragma unroll
+    for (int j = 0; j < SV; ++j)
+        if (o[j] >= 0)
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) { const float d = ld(v[j].v, k) - mean; q = __builtin_fmaf(d, d, q); }
+    const float var = block_sum_1024(q, lds) / (float)M;
+    const float invstd = 1.0f / sqrtf(var + eps);
+    if (threadIdx.x == 0) {
+        save_mean[c] = mean;
+        save_invstd[c] = invstd;
+        if (run_mean) {
+            const float unbiased = M > 1 ? var * ((float)M / (float)(M - 1)) : var;
+            run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * mean;
+            run_var[c] = (1.0f - momentum) * run_var[c] + momentum * unbiased;
+        }
+    }
+    const float scale = gamma[c] * invstd, shift = beta[c] - mean * scale;
+#pragma unroll
+    for (int j = 0; j < SV; ++j) {
+        if (o[j] < 0) continue;
+        Vec4<T> rv = {};
+        if (res) rv = *reinterpret_cast<const Vec4<T> *>(res + o[j]);
+        Vec4<T> w;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            float f = __builtin_fmaf(ld(v[j].v, k), scale, shift);
+            if (res) f += ld(rv.v, k);
+            st(w.v, k, (relu && f < 0.f) ? 0.f : f);
+        }
+        *reinterpret_cast<Vec4<T> *>(y + o[j]) = w;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(SB) void bn_small_bwd_kernel(const T *__restrict__ dy, const T *__restrict__ y,
+                                                          const T *__restrict__ x, const float *__restrict__ gamma,
+                                                          const float *__restrict__ save_mean,
+                                                          const float *__restrict__ save_invstd, int C, int HW, int B,
+                                                          int relu, T *__restrict__ dx, T *__restrict__ dres,
+                                                          float *__restrict__ dgamma, float *__restrict__ dbeta)
+{
+    __shared__ float lds[SB / 64];
+    const int c = blockIdx.x, M = B * HW;
+    const float mean = save_mean[c], invstd = save_invstd[c];
+    long long o[SV];
+    float dz[SV][VEC], xh[SV][VEC];
+    float a = 0.f, q = 0.f;
+#pragma unroll
+    for (int j = 0; j < SV; ++j) {
+        o[j] = small_offset(j, c, C, HW, M);
+        if (o[j] < 0) continue;
+        const Vec4<T> vd = *reinterpret_cast<const Vec4<T> *>(dy + o[j]);
+        const Vec4<T> vy = *reinterpret_cast<const Vec4<T> *>(y + o[j]);
+        const Vec4<T> vx = *reinterpret_cast<const Vec4<T> *>(x + o[j]);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            dz[j][k] = (relu && !(ld(vy.v, k) > 0.f)) ? 0.f : ld(vd.v, k);
+            xh[j][k] = (ld(vx.v, k) - mean) * invstd;
+            a += dz[j][k];
+            q = __builtin_fmaf(dz[j][k], xh[j][k], q);
+        }
+    }
+    a = block_sum_1024(a, lds);
+    q = block_sum_1024(q, lds);
+    if (threadIdx.x == 0) {
+        dbeta[c] = a;
+        dgamma[c] = q;
+    }
+    const float k0 = gamma[c] * invstd, mdz = a / (float)M, mdzx = q / (float)M;
+#pragma unroll
+    for (int j = 0; j < SV; ++j) {
+        if (o[j] < 0) continue;
+        Vec4<T> wx, wr;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            st(wx.v, k, k0 * (dz[j][k] - mdz - xh[j][k] * mdzx));
+            st(wr.v, k, dz[j][k]);
+        }
+        *reinterpret_cast<Vec4<T> *>(dx + o[j]) = wx;
+        if (dres) *reinterpret_cast<Vec4<T> *>(dres + o[j]) = wr;
+    }
+}
+
+static inline bool small_map(int B, int HW) { return (HW % VEC) == 0 && (long long)B * HW <= SMALL_MAX; }
+
 static inline int spans_per_plane(int HW) { return (HW + SPAN - 1) / SPAN; }
 
 }  // namespace mdx
@@ -260,6 +401,17 @@ MDX_EXPORT int mdx_bn_act_fwd(const void *x, const void *res, const float *gamma
     const dim3 grid(C, B * K), block(NB);
     hipStream_t st = (hipStream_t)stream;
     float *part = (float *)workspace;
+    if (small_map(B, HW) && dtype <= 1) {
+        if (dtype == 0)
+            hipLaunchKernelGGL((bn_small_fwd_kernel<float>), dim3(C), dim3(SB), 0, st, (const float *)x, (const float *)res,
+                               gamma, beta, C, HW, B, eps, momentum, relu, (float *)y, save_mean, save_invstd, run_mean,
+                               run_var);
+        else
+            hipLaunchKernelGGL((bn_small_fwd_kernel<bf16n>), dim3(C), dim3(SB), 0, st, (const bf16n *)x,
+                               (const bf16n *)res, gamma, beta, C, HW, B, eps, momentum, relu, (bf16n *)y, save_mean,
+                               save_invstd, run_mean, run_var);
+        return check_launch();
+    }
     if (dtype == 0) {
         hipLaunchKernelGGL((bn_fwd_stats_kernel<float>), grid, block, 0, st, (const float *)x, C, HW, K, part);
         hipLaunchKernelGGL((bn_fwd_apply_kernel<float>), grid, block, 0, st, (const float *)x, (const float *)res, gamma,
@@ -289,6 +441,17 @@ MDX_EXPORT int mdx_bn_act_bwd(const void *dy, const void *y, const void *x, cons
     const dim3 grid(C, B * K), block(NB);
     hipStream_t st = (hipStream_t)stream;
     float *part = (float *)workspace;
+    if (small_map(B, HW) && dtype <= 1) {
+        if (dtype == 0)
+            hipLaunchKernelGGL((bn_small_bwd_kernel<float>), dim3(C), dim3(SB), 0, st, (const float *)dy, (const float *)y,
+                               (const float *)x, gamma, save_mean, save_invstd, C, HW, B, relu, (float *)dx, (float *)dres,
+                               dgamma, dbeta);
+        else
+            hipLaunchKernelGGL((bn_small_bwd_kernel<bf16n>), dim3(C), dim3(SB), 0, st, (const bf16n *)dy, (const bf16n *)y,
+                               (const bf16n *)x, gamma, save_mean, save_invstd, C, HW, B, relu, (bf16n *)dx, (bf16n *)dres,
+                               dgamma, dbeta);
+        return check_launch();
+    }
     if (dtype == 0) {
         hipLaunchKernelGGL((bn_bwd_stats_kernel<float>), grid, block, 0, st, (const float *)dy, (const float *)y,
                            (const float *)x, save_mean, save_invstd, C, HW, K, relu, part);

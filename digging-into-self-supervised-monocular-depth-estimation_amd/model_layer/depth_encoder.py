@@ -22,7 +22,7 @@ class BatchNorm2d(nn.BatchNorm2d):
     keys; the buffer is brought up to date whenever the state dict is taken.  momentum=None (cumulative average,
     which does read the counter) keeps the stock behaviour."""
 
-    fused_min_elements = 32768      # per channel (B*H*W); see act()
+    fused_min_elements = 0          # per channel (B*H*W): below it act() takes the torch ops (a test / A-B switch)
 
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
@@ -39,9 +39,8 @@ class BatchNorm2d(nn.BatchNorm2d):
     def act(self, x, residual=None, relu=True):
         """relu(self(x) + residual) -- on the GPU in training mode as the fused two-pass kernel pair of
         csrc/norm.hip (statistics pass + normalise/add/ReLU pass; backward likewise), else as the torch ops."""
-        # two launches of >= 5 us each way: worth it from ~32 K elements per channel up (forward 2.3x faster than
-        # MIOpen's batch norm + add + clamp on the 96x320 maps, 1.5x on 48x160; below that MIOpen's single-kernel
-        # variants win -- tools/normbench.py)
+        # csrc/norm.hip: one launch each way for maps up to 24 K elements per channel (kept in registers between the
+        # reduction and the apply step), two (statistics pass, apply pass) above -- tools/normbench.py
         fused = (self.training and x.is_cuda and self.track_running_stats and self.momentum is not None
                  and self.affine and x.dtype in (torch.float32, torch.bfloat16) and x.dim() == 4
                  and torch.is_grad_enabled() and x.shape[0] * x.shape[2] * x.shape[3] >= self.fused_min_elements)
