@@ -39,4 +39,7 @@ def options(argv=None):
     p.add_argument("--channels_last", action="store_true")
     p.add_argument("--synthetic_length", type=int, default=768)
     p.add_argument("--max_steps", type=int, default=0, help="stop an epoch early (0 = full epoch)")
+    p.add_argument("--miopen_find", action="store_true",
+                   help="cudnn.benchmark: MIOpen find mode (a search of minutes for shapes that are not in the "
+                        "shipped find-db; the default, immediate mode, already uses the db)")
     return p.parse_args(argv)

@@ -28,8 +28,8 @@ class trainer(object):
             torch.distributed.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
         self.rank = int(os.environ.get("RANK", "0"))
         from mdx.tuning import install_miopen_db
-        install_miopen_db(self.rank)          # tuned conv solvers for the default shapes; other shapes: find mode below
-        torch.backends.cudnn.benchmark = True
+        install_miopen_db(self.rank)          # tuned conv / batch-norm solvers for the default shapes (immediate mode)
+        torch.backends.cudnn.benchmark = bool(getattr(opt, "miopen_find", False))
         self.setting = setting(opt, self.device)
         self.compute = compute(opt, self.device)
         self.control = control(opt, self.device)
