@@ -507,11 +507,17 @@ def maxpool3s2(x):
 
 # ---- training-mode BatchNorm2d fused with residual add and ReLU (csrc/norm.hip) -----------------------------------
 class _BnAct(torch.autograd.Function):
+    """groups > 1: the batch is `groups` consecutive sub-batches, each normalised with its own statistics and the
+    running statistics updated once per sub-batch, in order -- exactly what `groups` separate calls of the module
+    would do (the pose network sees both frame pairs of a step in one batch this way)."""
+
     @staticmethod
-    def forward(ctx, x, res, weight, bias, running_mean, running_var, eps, momentum, relu):
+    def forward(ctx, x, res, weight, bias, running_mean, running_var, eps, momentum, relu, groups):
         x = x.contiguous()
         code = _glue_dtype(x, "bn_act")
         B, Cc, H, W = x.shape
+        if B % groups:
+            raise _lib.MdxError("bn_act: batch %d is not divisible into %d groups" % (B, groups))
         if res is not None:
             res = res.contiguous()
             if res.shape != x.shape or res.dtype != x.dtype:
@@ -519,42 +525,55 @@ class _BnAct(torch.autograd.Function):
                                     % (tuple(res.shape), res.dtype, tuple(x.shape), x.dtype))
         weight, bias = _f32c(weight), _f32c(bias)
         y = torch.empty_like(x)
-        save_mean = torch.empty(Cc, device=x.device, dtype=torch.float32)
-        save_invstd = torch.empty(Cc, device=x.device, dtype=torch.float32)
-        nws = lib().mdx_bn_workspace_bytes(B, Cc, H, W)
+        save_mean = torch.empty(groups, Cc, device=x.device, dtype=torch.float32)
+        save_invstd = torch.empty(groups, Cc, device=x.device, dtype=torch.float32)
+        Bg = B // groups
+        nws = lib().mdx_bn_workspace_bytes(Bg, Cc, H, W)
         ws = torch.empty(nws // 4 + 1, device=x.device, dtype=torch.float32)
-        check(lib().mdx_bn_act_fwd(
-            ptr(x, x.dtype), ptr(res, x.dtype) if res is not None else None, ptr(weight), ptr(bias),
-            ptr(running_mean) if running_mean is not None else None,
-            ptr(running_var) if running_var is not None else None, ptr(y, x.dtype), ptr(save_mean), ptr(save_invstd),
-            B, Cc, H, W, C.c_float(eps), C.c_float(momentum), int(relu), code, ptr(ws), C.c_size_t(nws), stream()),
-            "mdx_bn_act_fwd")
+        for g in range(groups):
+            sl = slice(g * Bg, (g + 1) * Bg)
+            check(lib().mdx_bn_act_fwd(
+                ptr(x[sl], x.dtype), ptr(res[sl], x.dtype) if res is not None else None, ptr(weight), ptr(bias),
+                ptr(running_mean) if running_mean is not None else None,
+                ptr(running_var) if running_var is not None else None, ptr(y[sl], x.dtype), ptr(save_mean[g]),
+                ptr(save_invstd[g]), Bg, Cc, H, W, C.c_float(eps), C.c_float(momentum), int(relu), code, ptr(ws),
+                C.c_size_t(nws), stream()), "mdx_bn_act_fwd")
         ctx.save_for_backward(x, y, weight, save_mean, save_invstd)
-        ctx.meta = (bool(relu), res is not None)
+        ctx.meta = (bool(relu), res is not None, groups)
         ctx.mark_non_differentiable(*[t for t in (running_mean, running_var) if t is not None])
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, y, weight, save_mean, save_invstd = ctx.saved_tensors
-        relu, has_res = ctx.meta
+        relu, has_res, groups = ctx.meta
         B, Cc, H, W = x.shape
+        Bg = B // groups
         dy = dy.contiguous().to(x.dtype)
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if has_res else None
-        dgamma = torch.empty(Cc, device=x.device, dtype=torch.float32)
-        dbeta = torch.empty(Cc, device=x.device, dtype=torch.float32)
-        nws = lib().mdx_bn_workspace_bytes(B, Cc, H, W)
+        dgamma = torch.empty(groups, Cc, device=x.device, dtype=torch.float32)
+        dbeta = torch.empty(groups, Cc, device=x.device, dtype=torch.float32)
+        nws = lib().mdx_bn_workspace_bytes(Bg, Cc, H, W)
         ws = torch.empty(nws // 4 + 1, device=x.device, dtype=torch.float32)
-        check(lib().mdx_bn_act_bwd(
-            ptr(dy, x.dtype), ptr(y, x.dtype), ptr(x, x.dtype), ptr(weight), ptr(save_mean), ptr(save_invstd),
-            ptr(dx, x.dtype), ptr(dres, x.dtype) if has_res else None, ptr(dgamma), ptr(dbeta), B, Cc, H, W, int(relu),
-            _DTYPE_CODE[x.dtype], ptr(ws), C.c_size_t(nws), stream()), "mdx_bn_act_bwd")
-        return dx, dres, dgamma, dbeta, None, None, None, None, None
+        for g in range(groups):
+            sl = slice(g * Bg, (g + 1) * Bg)
+            check(lib().mdx_bn_act_bwd(
+                ptr(dy[sl], x.dtype), ptr(y[sl], x.dtype), ptr(x[sl], x.dtype), ptr(weight), ptr(save_mean[g]),
+                ptr(save_invstd[g]), ptr(dx[sl], x.dtype), ptr(dres[sl], x.dtype) if has_res else None, ptr(dgamma[g]),
+                ptr(dbeta[g]), Bg, Cc, H, W, int(relu), _DTYPE_CODE[x.dtype], ptr(ws), C.c_size_t(nws), stream()),
+                "mdx_bn_act_bwd")
+        if groups > 1:
+            dgamma, dbeta = dgamma.sum(0), dbeta.sum(0)
+        else:
+            dgamma, dbeta = dgamma[0], dbeta[0]
+        return dx, dres, dgamma, dbeta, None, None, None, None, None, None
 
 
-def bn_act(x, weight, bias, running_mean, running_var, eps=1e-5, momentum=0.1, residual=None, relu=True):
-    """Training-mode batch norm over (B,H,W) of x [B,C,H,W] with batch statistics, then `+ residual`, then ReLU, in
-    two passes over x (csrc/norm.hip).  Updates running_mean / running_var in place like
-    torch.nn.functional.batch_norm(training=True).  float32 or bfloat16 activations, float32 parameters."""
-    return _BnAct.apply(x, residual, weight, bias, running_mean, running_var, float(eps), float(momentum), bool(relu))
+def bn_act(x, weight, bias, running_mean, running_var, eps=1e-5, momentum=0.1, residual=None, relu=True, groups=1):
+    """Training-mode batch norm over (B,H,W) of x [B,C,H,W] with batch statistics, then `+ residual`, then ReLU
+    (csrc/norm.hip).  Updates running_mean / running_var in place like
+    torch.nn.functional.batch_norm(training=True).  float32 or bfloat16 activations, float32 parameters.
+    groups: number of consecutive sub-batches normalised independently (see _BnAct)."""
+    return _BnAct.apply(x, residual, weight, bias, running_mean, running_var, float(eps), float(momentum), bool(relu),
+                        int(groups))

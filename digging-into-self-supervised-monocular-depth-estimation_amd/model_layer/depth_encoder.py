@@ -23,6 +23,23 @@ class BatchNorm2d(nn.BatchNorm2d):
     which does read the counter) keeps the stock behaviour."""
 
     fused_min_elements = 0          # per channel (B*H*W): below it act() takes the torch ops (a test / A-B switch)
+    _batch_groups = 1               # see batch_groups()
+
+    @classmethod
+    def batch_groups(cls, groups):
+        """Context manager: inside it every BatchNorm2d treats its input batch as `groups` consecutive sub-batches,
+        each with its own batch statistics and its own running-statistics update -- the result of calling the
+        network once per sub-batch, from ONE pass of the convolutions over the whole batch."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            prev, cls._batch_groups = cls._batch_groups, int(groups)
+            try:
+                yield
+            finally:
+                cls._batch_groups = prev
+        return scope()
 
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
@@ -31,6 +48,12 @@ class BatchNorm2d(nn.BatchNorm2d):
     def forward(self, x):
         if self.momentum is None or not self.track_running_stats:
             return super().forward(x)
+        groups = self._batch_groups if self.training else 1
+        if groups > 1:
+            return torch.cat([self._norm(c) for c in x.chunk(groups)])
+        return self._norm(x)
+
+    def _norm(self, x):
         if self.training:
             self._pending_batches += 1
         return TF.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, self.training,
@@ -43,18 +66,19 @@ class BatchNorm2d(nn.BatchNorm2d):
         # reduction and the apply step), two (statistics pass, apply pass) above -- tools/normbench.py
         fused = (self.training and x.is_cuda and self.track_running_stats and self.momentum is not None
                  and self.affine and x.dtype in (torch.float32, torch.bfloat16) and x.dim() == 4
-                 and torch.is_grad_enabled() and x.shape[0] * x.shape[2] * x.shape[3] >= self.fused_min_elements)
+                 and torch.is_grad_enabled() and x.shape[0] % self._batch_groups == 0
+                 and x.shape[0] * x.shape[2] * x.shape[3] >= self.fused_min_elements)
         if not fused:
             out = self(x)
             if residual is not None:
                 out = out + residual
             return TF.relu(out) if relu else out
         from mdx import functional as F
-        self._pending_batches += 1
+        self._pending_batches += self._batch_groups
         if residual is not None and residual.dtype != x.dtype:
             residual = residual.to(x.dtype)
         return F.bn_act(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps, self.momentum,
-                        residual=residual, relu=relu)
+                        residual=residual, relu=relu, groups=self._batch_groups)
 
     def _flush_counter(self):
         if self._pending_batches and self.num_batches_tracked is not None:

@@ -30,6 +30,8 @@ class compute(object):
         # (processor.py:195) -- same stream of numbers as the reference for a given torch seed.
         self.noise_mode = _opt(opt, "noise", "device")
         self.amp = _opt(opt, "amp", "none")
+        # both frame pairs through the separate pose network in one batch (same numbers, see below)
+        self.batch_pose_pairs = _opt(opt, "batch_pose_pairs", True)
 
     # -- networks ---------------------------------------------------------------------------------
     def _autocast(self):
@@ -57,7 +59,9 @@ class compute(object):
     def forward_pose(self, inputs, outputs, setting):
         opt = self.opt
         with self._autocast():
-            if self.num_pose_frames == 2:
+            if self.num_pose_frames == 2 and opt.pose_type == "separate" and self.batch_pose_pairs:
+                self._forward_pose_pairs_batched(inputs, outputs, setting)
+            elif self.num_pose_frames == 2:
                 for frame_id in opt.frame_ids[1:]:
                     if frame_id == "s":
                         continue
@@ -90,6 +94,30 @@ class compute(object):
                         outputs[("c2c", frame_id, 0)] = param2matrix(
                             axisangle=axisangle[:, index].float(), translation=translation[:, index].float())
         return inputs, outputs
+
+    def _forward_pose_pairs_batched(self, inputs, outputs, setting):
+        """The frame pairs of processor.py:61-83 (one pose-network call per source frame) as ONE pass of the
+        convolutions over the concatenated pairs.  The pose encoder's batch norms normalise each pair with its own
+        statistics and update the running statistics pair by pair (BatchNorm2d.batch_groups), so every number is
+        the one the per-pair loop produces; the parameter gradients of the two uses are summed inside the
+        weight-gradient kernels instead of by ~200 small accumulation kernels."""
+        from model_layer.depth_encoder import BatchNorm2d
+        opt = self.opt
+        frames = [f for f in opt.frame_ids[1:] if f != "s"]
+        pairs = []
+        for frame_id in frames:
+            first, second = (frame_id, 0) if frame_id < 0 else (0, frame_id)
+            pairs.append(torch.cat([inputs[("color_aug", first, 0)], inputs[("color_aug", second, 0)]], 1))
+        n = pairs[0].shape[0]
+        with BatchNorm2d.batch_groups(len(pairs)):
+            feats = setting.model["pose_encoder"](torch.cat(pairs, 0))
+        axisangle, translation = setting.model["pose_decoder"]([feats])
+        for k, frame_id in enumerate(frames):
+            aa, tr = axisangle[k * n:(k + 1) * n], translation[k * n:(k + 1) * n]
+            outputs[("R", frame_id, 0)] = aa
+            outputs[("T", frame_id, 0)] = tr
+            outputs[("c2c", frame_id, 0)] = param2matrix(axisangle=aa[:, 0].float(), translation=tr[:, 0].float(),
+                                                         invert=(frame_id < 0))
 
     # -- geometry ---------------------------------------------------------------------------------
     def _transformation(self, inputs, outputs, frame_id, depth_fn):

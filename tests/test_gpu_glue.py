@@ -196,3 +196,35 @@ def test_encoder_fused_norm_path_equals_module_path(layers, monkeypatch):
         # weight-gradient kernels sum with atomics): compare in the Frobenius norm, with an absolute floor
         err, scale = float((p.grad - q.grad).norm()), float(q.grad.norm())
         assert err <= (2e-2 if layers == 18 else 1e-1) * scale + 1e-5, "%s: err %.3g scale %.3g" % (n, err, scale)
+
+
+def test_batched_pose_pairs_equal_the_loop_on_gpu():
+    """forward_pose on the GPU: one batched pass (grouped fused batch norms) == one call per pair."""
+    import types
+    from model_layer import ResnetEncoder, PoseDecoder
+    from model_tool.processor import compute
+    opt = types.SimpleNamespace(frame_ids=[0, -1, 1], pose_frames="pair", pose_type="separate", batch=3)
+    g = torch.Generator().manual_seed(1)
+    inputs = {("color_aug", f, 0): torch.rand(3, 3, 64, 128, generator=g).cuda() for f in (0, -1, 1)}
+    res = {}
+    for batched in (True, False):
+        torch.manual_seed(7)
+        enc = ResnetEncoder(18, False, num_input_images=2).cuda().train()
+        dec = PoseDecoder(enc.num_ch_enc, 1, 2).cuda().train()
+        st = types.SimpleNamespace(model={"pose_encoder": enc, "pose_decoder": dec})
+        opt.batch_pose_pairs = batched
+        _, out = compute(opt, "cuda").forward_pose(dict(inputs), {}, st)
+        sum(out[("c2c", f, 0)].square().sum() for f in (-1, 1)).backward()
+        res[batched] = (out, st)
+    (oa, sa), (ob, sb) = res[True], res[False]
+    for f in (-1, 1):
+        torch.testing.assert_close(oa[("c2c", f, 0)], ob[("c2c", f, 0)], rtol=1e-4, atol=1e-5)
+    da, db = sa.model["pose_encoder"].state_dict(), sb.model["pose_encoder"].state_dict()
+    for k in da:
+        torch.testing.assert_close(da[k].float(), db[k].float(), rtol=1e-4, atol=1e-5, msg=k)
+    for name in ("pose_encoder", "pose_decoder"):
+        for (n, p), (_, q) in zip(sa.model[name].named_parameters(), sb.model[name].named_parameters()):
+            if q.grad is None:
+                continue
+            err, scale = float((p.grad - q.grad).norm()), float(q.grad.norm())
+            assert err <= 2e-2 * scale + 1e-6, "%s.%s: %g vs %g" % (name, n, err, scale)

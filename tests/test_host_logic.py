@@ -115,7 +115,8 @@ def test_depth_metrics():
 def test_pose_driver_pair_ordering_and_invert_flag():
     """compute.forward_pose (reference processor.py:99-114): [f,0] for f<0 (inverted), [0,f] for f>0."""
     from model_tool.processor import compute
-    opt = types.SimpleNamespace(frame_ids=[0, -1, 1, "s"], pose_frames="pair", pose_type="separate", batch=1)
+    opt = types.SimpleNamespace(frame_ids=[0, -1, 1, "s"], pose_frames="pair", pose_type="separate", batch=1,
+                                batch_pose_pairs=False)      # the reference's loop: one call per pair
     seen = []
 
     class Enc(torch.nn.Module):
@@ -134,6 +135,19 @@ def test_pose_driver_pair_ordering_and_invert_flag():
     aa, tr = torch.full((1, 1, 3), 0.01), torch.full((1, 1, 3), 0.02)
     np.testing.assert_allclose(out[("c2c", -1, 0)].numpy(), param2matrix(aa, tr, True).numpy())
     np.testing.assert_allclose(out[("c2c", 1, 0)].numpy(), param2matrix(aa, tr, False).numpy())
+    # default: the same pairs, in the same order, stacked along the batch of ONE call
+    opt.batch_pose_pairs = True
+    del seen[:]
+
+    class Dec2(torch.nn.Module):
+        def forward(self, feats):
+            n = feats[0][0].shape[0]
+            return torch.full((n, 2, 1, 3), 0.01), torch.full((n, 2, 1, 3), 0.02)
+    st = types.SimpleNamespace(model={"pose_encoder": Enc(), "pose_decoder": Dec2()})
+    _, out2 = compute(opt, "cpu").forward_pose(inputs, {}, st)
+    assert len(seen) == 1 and seen[0].tolist() == [[-1.0, 0.0], [0.0, 1.0]]
+    for f in (-1, 1):
+        np.testing.assert_allclose(out2[("c2c", f, 0)].numpy(), out[("c2c", f, 0)].numpy())
 
 
 def test_miopen_find_db_install(tmp_path, monkeypatch):
@@ -175,3 +189,43 @@ def test_batchnorm_host_counter_keeps_state_dict_contract():
     x = torch.randn(2, 5, 3, 3)
     torch.testing.assert_close(a(x), b(x))
     assert int(a.state_dict()["num_batches_tracked"]) == 3
+
+
+def _pose_setting(seed=7):
+    from model_layer import ResnetEncoder, PoseDecoder
+    torch.manual_seed(seed)
+    enc = ResnetEncoder(18, False, num_input_images=2).train()
+    dec = PoseDecoder(enc.num_ch_enc, 1, 2).train()
+    return types.SimpleNamespace(model={"pose_encoder": enc, "pose_decoder": dec})
+
+
+def test_batched_pose_pairs_equal_the_per_pair_loop():
+    """compute.forward_pose: both frame pairs through the separate pose network in ONE batch (batch norms grouped per
+    pair) == the reference's loop of one call per pair (processor.py:61-83): poses, running statistics, gradients."""
+    from model_tool.processor import compute
+    opt = types.SimpleNamespace(frame_ids=[0, -1, 1], pose_frames="pair", pose_type="separate", batch=2)
+    g = torch.Generator().manual_seed(1)
+    inputs = {("color_aug", f, 0): torch.rand(2, 3, 64, 96, generator=g) for f in (0, -1, 1)}
+    res = {}
+    for batched in (True, False):
+        st = _pose_setting()
+        opt.batch_pose_pairs = batched
+        cp = compute(opt, "cpu")
+        _, out = cp.forward_pose(dict(inputs), {}, st)
+        loss = sum(out[("c2c", f, 0)].square().sum() for f in (-1, 1))
+        loss.backward()
+        res[batched] = (out, st)
+    (oa, sa), (ob, sb) = res[True], res[False]
+    for f in (-1, 1):
+        for key in ("R", "T", "c2c"):
+            torch.testing.assert_close(oa[(key, f, 0)], ob[(key, f, 0)], rtol=1e-5, atol=1e-6)
+    da, db = sa.model["pose_encoder"].state_dict(), sb.model["pose_encoder"].state_dict()
+    for k in da:
+        torch.testing.assert_close(da[k].float(), db[k].float(), rtol=1e-5, atol=1e-6, msg=k)
+    assert int(da["encoder.bn1.num_batches_tracked"]) == 2
+    for name in ("pose_encoder", "pose_decoder"):
+        for (n, p), (_, q) in zip(sa.model[name].named_parameters(), sb.model[name].named_parameters()):
+            if q.grad is None:
+                continue
+            err, scale = float((p.grad - q.grad).norm()), float(q.grad.norm())
+            assert err <= 1e-3 * scale + 1e-7, "%s.%s: %g vs %g" % (name, n, err, scale)
