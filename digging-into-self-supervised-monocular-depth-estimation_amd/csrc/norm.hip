@@ -194,8 +194,9 @@ __global__ __launch_bounds__(NB) void bn_bwd_apply_kernel(const T *__restrict__ 
                                                           const float *__restrict__ save_mean,
                                                           const float *__restrict__ save_invstd,
                                                           const float *__restrict__ part, int C, int HW, int K, int B,
-                                                          int relu, T *__restrict__ dx, T *__restrict__ dres,
-                                                          float *__restrict__ dgamma, float *__restrict__ dbeta)
+                                                          int relu, int accum, T *__restrict__ dx,
+                                                          T *__restrict__ dres, float *__restrict__ dgamma,
+                                                          float *__restrict__ dbeta)
 {
     const SpanId s = span_id(C, HW, K);
     double a = 0.0, q = 0.0;
@@ -204,8 +205,8 @@ __global__ __launch_bounds__(NB) void bn_bwd_apply_kernel(const T *__restrict__ 
         q += (double)part[((size_t)s.c * gridDim.y + i) * 2 + 1];
     }
     if (blockIdx.y == 0 && threadIdx.x == 0) {
-        dbeta[s.c] = (float)a;
-        dgamma[s.c] = (float)q;
+        dbeta[s.c] = (accum ? dbeta[s.c] : 0.f) + (float)a;
+        dgamma[s.c] = (accum ? dgamma[s.c] : 0.f) + (float)q;
     }
     const double M = (double)B * HW;
     const float mean = save_mean[s.c], invstd = save_invstd[s.c];
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(SB) void bn_small_bwd_kernel(const T *__restrict__ 
                                                           const T *__restrict__ x, const float *__restrict__ gamma,
                                                           const float *__restrict__ save_mean,
                                                           const float *__restrict__ save_invstd, int C, int HW, int B,
-                                                          int relu, T *__restrict__ dx, T *__restrict__ dres,
+                                                          int relu, int accum, T *__restrict__ dx, T *__restrict__ dres,
                                                           float *__restrict__ dgamma, float *__restrict__ dbeta)
 {
     __shared__ float lds[SB / 64];
@@ -354,8 +355,8 @@ __global__ __launch_bounds__(SB) void bn_small_bwd_kernel(const T *__restrict__ 
     a = block_sum_1024(a, lds);
     q = block_sum_1024(q, lds);
     if (threadIdx.x == 0) {
-        dbeta[c] = a;
-        dgamma[c] = q;
+        dbeta[c] = (accum ? dbeta[c] : 0.f) + a;
+        dgamma[c] = (accum ? dgamma[c] : 0.f) + q;
     }
     const float k0 = gamma[c] * invstd, mdz = a / (float)M, mdzx = q / (float)M;
 #pragma unroll
@@ -430,7 +431,8 @@ MDX_EXPORT int mdx_bn_act_fwd(const void *x, const void *res, const float *gamma
 
 MDX_EXPORT int mdx_bn_act_bwd(const void *dy, const void *y, const void *x, const float *gamma, const float *save_mean,
                               const float *save_invstd, void *dx, void *dres, float *dgamma, float *dbeta, int B, int C,
-                              int H, int W, int relu, int dtype, void *workspace, size_t workspace_bytes, void *stream)
+                              int H, int W, int relu, int accumulate, int dtype, void *workspace, size_t workspace_bytes,
+                              void *stream)
 {
     if (!dy || !y || !x || !gamma || !save_mean || !save_invstd || !dx || !dgamma || !dbeta || !workspace)
         return MDX_ERR_NULL_POINTER;
@@ -444,25 +446,25 @@ MDX_EXPORT int mdx_bn_act_bwd(const void *dy, const void *y, const void *x, cons
     if (small_map(B, HW) && dtype <= 1) {
         if (dtype == 0)
             hipLaunchKernelGGL((bn_small_bwd_kernel<float>), dim3(C), dim3(SB), 0, st, (const float *)dy, (const float *)y,
-                               (const float *)x, gamma, save_mean, save_invstd, C, HW, B, relu, (float *)dx, (float *)dres,
-                               dgamma, dbeta);
+                               (const float *)x, gamma, save_mean, save_invstd, C, HW, B, relu, accumulate, (float *)dx,
+                               (float *)dres, dgamma, dbeta);
         else
             hipLaunchKernelGGL((bn_small_bwd_kernel<bf16n>), dim3(C), dim3(SB), 0, st, (const bf16n *)dy, (const bf16n *)y,
-                               (const bf16n *)x, gamma, save_mean, save_invstd, C, HW, B, relu, (bf16n *)dx, (bf16n *)dres,
-                               dgamma, dbeta);
+                               (const bf16n *)x, gamma, save_mean, save_invstd, C, HW, B, relu, accumulate, (bf16n *)dx,
+                               (bf16n *)dres, dgamma, dbeta);
         return check_launch();
     }
     if (dtype == 0) {
         hipLaunchKernelGGL((bn_bwd_stats_kernel<float>), grid, block, 0, st, (const float *)dy, (const float *)y,
                            (const float *)x, save_mean, save_invstd, C, HW, K, relu, part);
         hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), grid, block, 0, st, (const float *)dy, (const float *)y,
-                           (const float *)x, gamma, save_mean, save_invstd, part, C, HW, K, B, relu, (float *)dx,
+                           (const float *)x, gamma, save_mean, save_invstd, part, C, HW, K, B, relu, accumulate, (float *)dx,
                            (float *)dres, dgamma, dbeta);
     } else if (dtype == 1) {
         hipLaunchKernelGGL((bn_bwd_stats_kernel<bf16n>), grid, block, 0, st, (const bf16n *)dy, (const bf16n *)y,
                            (const bf16n *)x, save_mean, save_invstd, C, HW, K, relu, part);
         hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16n>), grid, block, 0, st, (const bf16n *)dy, (const bf16n *)y,
-                           (const bf16n *)x, gamma, save_mean, save_invstd, part, C, HW, K, B, relu, (bf16n *)dx,
+                           (const bf16n *)x, gamma, save_mean, save_invstd, part, C, HW, K, B, relu, accumulate, (bf16n *)dx,
                            (bf16n *)dres, dgamma, dbeta);
     } else {
         return MDX_ERR_BAD_SHAPE;

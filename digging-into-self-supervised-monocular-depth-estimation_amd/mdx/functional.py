@@ -552,21 +552,17 @@ class _BnAct(torch.autograd.Function):
         dy = dy.contiguous().to(x.dtype)
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if has_res else None
-        dgamma = torch.empty(groups, Cc, device=x.device, dtype=torch.float32)
-        dbeta = torch.empty(groups, Cc, device=x.device, dtype=torch.float32)
+        dgamma = torch.empty(Cc, device=x.device, dtype=torch.float32)
+        dbeta = torch.empty(Cc, device=x.device, dtype=torch.float32)
         nws = lib().mdx_bn_workspace_bytes(Bg, Cc, H, W)
         ws = torch.empty(nws // 4 + 1, device=x.device, dtype=torch.float32)
         for g in range(groups):
             sl = slice(g * Bg, (g + 1) * Bg)
             check(lib().mdx_bn_act_bwd(
                 ptr(dy[sl], x.dtype), ptr(y[sl], x.dtype), ptr(x[sl], x.dtype), ptr(weight), ptr(save_mean[g]),
-                ptr(save_invstd[g]), ptr(dx[sl], x.dtype), ptr(dres[sl], x.dtype) if has_res else None, ptr(dgamma[g]),
-                ptr(dbeta[g]), Bg, Cc, H, W, int(relu), _DTYPE_CODE[x.dtype], ptr(ws), C.c_size_t(nws), stream()),
-                "mdx_bn_act_bwd")
-        if groups > 1:
-            dgamma, dbeta = dgamma.sum(0), dbeta.sum(0)
-        else:
-            dgamma, dbeta = dgamma[0], dbeta[0]
+                ptr(save_invstd[g]), ptr(dx[sl], x.dtype), ptr(dres[sl], x.dtype) if has_res else None, ptr(dgamma),
+                ptr(dbeta), Bg, Cc, H, W, int(relu), int(g > 0), _DTYPE_CODE[x.dtype], ptr(ws), C.c_size_t(nws),
+                stream()), "mdx_bn_act_bwd")
         return dx, dres, dgamma, dbeta, None, None, None, None, None, None
 
 

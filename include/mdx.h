@@ -227,10 +227,11 @@ int mdx_bn_act_fwd(const void *x, const void *res, const float *gamma, const flo
                    float *run_var, void *y, float *save_mean, float *save_invstd, int B, int C, int H, int W,
                    float eps, float momentum, int relu, int dtype, void *workspace, size_t workspace_bytes,
                    void *stream);
-/* dz = dy * (y > 0) when relu; dx, d(res) = dz (dres NULL when there was no residual), dgamma, dbeta [C]. */
+/* dz = dy * (y > 0) when relu; dx, d(res) = dz (dres NULL when there was no residual), dgamma, dbeta [C]
+ * (accumulate != 0: added to what dgamma / dbeta hold -- a batch processed as several sub-batches). */
 int mdx_bn_act_bwd(const void *dy, const void *y, const void *x, const float *gamma, const float *save_mean,
                    const float *save_invstd, void *dx, void *dres, float *dgamma, float *dbeta, int B, int C, int H,
-                   int W, int relu, int dtype, void *workspace, size_t workspace_bytes, void *stream);
+                   int W, int relu, int accumulate, int dtype, void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }
