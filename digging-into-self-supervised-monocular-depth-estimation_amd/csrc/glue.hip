@@ -43,8 +43,8 @@ constexpr int RPT = 4;           // rows per thread (GY apart): four independent
 // ---- decoder glue, forward.  grid: (ceil(Wp/64), ceil(Hp/4), B*(C1+C2)) ----
 template <typename TI, typename TO>
 __global__ __launch_bounds__(GX *GY) void decoder_glue_fwd_kernel(const TI *__restrict__ raw, const TI *__restrict__ skip,
-                                                                   TO *__restrict__ out, int C1, int C2, int h, int w,
-                                                                   int up, int elu)
+                                                                   const float *__restrict__ bias, TO *__restrict__ out,
+                                                                   int C1, int C2, int h, int w, int up, int elu)
 {
     const int u = up ? 2 : 1;
     const int H = h * u, W = w * u, Hp = H + 2, Wp = W + 2;
@@ -64,7 +64,12 @@ __global__ __launch_bounds__(GX *GY) void decoder_glue_fwd_kernel(const TI *__re
     for (int r = 0; r < RPT; ++r) {
         const int yo = y0 + r * GY;
         if (yo >= Hp) break;
-        out[((size_t)bc * Hp + yo) * Wp + xo] = from_float<TO>((c < C1 && elu) ? elu1(v[r]) : v[r]);
+        float f = v[r];
+        if (c < C1) {
+            if (bias) f += bias[c];          // the convolution ran without its bias: added here, on the way in
+            if (elu) f = elu1(f);
+        }
+        out[((size_t)bc * Hp + yo) * Wp + xo] = from_float<TO>(f);
     }
 }
 
@@ -88,15 +93,19 @@ template <typename T> __device__ __forceinline__ float fold_pad(const T *__restr
 // ---- decoder glue, backward w.r.t. raw.  grid: (ceil(w/64), ceil(h/4), B*C1) ----
 template <typename TI, typename TO>
 __global__ __launch_bounds__(GX *GY) void decoder_glue_bwd_raw_kernel(const TO *__restrict__ gout, const TI *__restrict__ raw,
-                                                                       TI *__restrict__ graw, int C1, int C2, int h, int w,
-                                                                       int up, int elu)
+                                                                       const float *__restrict__ bias, TI *__restrict__ graw,
+                                                                       float *__restrict__ bias_part, int C1, int C2, int h,
+                                                                       int w, int up, int elu)
 {
+    __shared__ float lds[GX * GY / 64];
     const int u = up ? 2 : 1;
     const int H = h * u, W = w * u;
-    const int xx = blockIdx.x * GX + threadIdx.x, y0 = blockIdx.y * (GY * RPT) + threadIdx.y;
-    if (xx >= w) return;
+    const int xx_raw = blockIdx.x * GX + threadIdx.x, y0 = blockIdx.y * (GY * RPT) + threadIdx.y;
+    const bool in_x = xx_raw < w;
+    const int xx = in_x ? xx_raw : 0;
     const int bc = blockIdx.z, b = bc / C1, c = bc - b * C1;
     const TO *gp = gout + ((size_t)b * (C1 + C2) + c) * (size_t)(H + 2) * (W + 2);
+    const float bv = bias ? bias[c] : 0.f;
     float g[RPT], rv[RPT];
 #pragma unroll
     for (int r = 0; r < RPT; ++r) {
@@ -104,14 +113,43 @@ __global__ __launch_bounds__(GX *GY) void decoder_glue_bwd_raw_kernel(const TO *
         g[r] = 0.f;
         for (int dy = 0; dy < u; ++dy)
             for (int dx = 0; dx < u; ++dx) g[r] += fold_pad(gp, u * yy + dy, u * xx + dx, H, W);
-        rv[r] = elu ? to_float(raw[((size_t)bc * h + yy) * w + xx]) : 1.f;
+        rv[r] = elu ? to_float(raw[((size_t)bc * h + yy) * w + xx]) + bv : 1.f;
     }
+    float bsum = 0.f;
 #pragma unroll
     for (int r = 0; r < RPT; ++r) {
         const int yy = y0 + r * GY;
-        if (yy >= h) break;
-        graw[((size_t)bc * h + yy) * w + xx] = from_float<TI>((elu && !(rv[r] > 0.f)) ? g[r] * __expf(rv[r]) : g[r]);
+        if (yy >= h || !in_x) continue;
+        const float gr = (elu && !(rv[r] > 0.f)) ? g[r] * __expf(rv[r]) : g[r];
+        const TI stored = from_float<TI>(gr);
+        graw[((size_t)bc * h + yy) * w + xx] = stored;
+        bsum += to_float(stored);
     }
+    if (bias_part) {
+        // d(bias)[c] = sum of graw over (b, y, x): one partial per block, summed in fixed order by the finish kernel
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) bsum += __shfl_down(bsum, off, 64);
+        const int tid = threadIdx.y * GX + threadIdx.x;
+        if ((tid & 63) == 0) lds[tid >> 6] = bsum;
+        __syncthreads();
+        if (tid == 0)
+            bias_part[((size_t)bc * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = (lds[0] + lds[1]) + (lds[2] + lds[3]);
+    }
+}
+
+// d(bias)[c] = sum over b and the blocks of plane (b, c): one wave per channel, fixed order
+__global__ __launch_bounds__(64) void decoder_glue_bias_finish_kernel(const float *__restrict__ part, int B, int C1,
+                                                                       int nblk, float *__restrict__ dbias)
+{
+    const int c = blockIdx.x;
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float *p = part + ((size_t)b * C1 + c) * nblk;
+        for (int i = threadIdx.x; i < nblk; i += 64) acc += p[i];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (threadIdx.x == 0) dbias[c] = acc;
 }
 
 // ---- decoder glue, backward w.r.t. skip.  grid: (ceil(W/64), ceil(H/4), B*C2) ----
@@ -209,8 +247,8 @@ using namespace mdx;
 // dtype codes of the glue entry points
 enum { MDX_F32 = 0, MDX_BF16 = 1 };
 
-MDX_EXPORT int mdx_decoder_glue_fwd(const void *raw, const void *skip, void *out, int B, int C1, int C2, int h, int w,
-                                    int upsample, int elu, int in_dtype, int out_dtype, void *stream)
+MDX_EXPORT int mdx_decoder_glue_fwd(const void *raw, const void *skip, const float *bias, void *out, int B, int C1, int C2,
+                                    int h, int w, int upsample, int elu, int in_dtype, int out_dtype, void *stream)
 {
     if (!raw || !out || (C2 > 0 && !skip)) return MDX_ERR_NULL_POINTER;
     const int u = upsample ? 2 : 1;
@@ -220,22 +258,31 @@ MDX_EXPORT int mdx_decoder_glue_fwd(const void *raw, const void *skip, void *out
     hipStream_t st = (hipStream_t)stream;
     if (in_dtype == MDX_F32 && out_dtype == MDX_F32)
         hipLaunchKernelGGL((decoder_glue_fwd_kernel<float, float>), grid, block, 0, st, (const float *)raw,
-                           (const float *)skip, (float *)out, C1, C2, h, w, upsample, elu);
+                           (const float *)skip, bias, (float *)out, C1, C2, h, w, upsample, elu);
     else if (in_dtype == MDX_BF16 && out_dtype == MDX_BF16)
         hipLaunchKernelGGL((decoder_glue_fwd_kernel<bf16, bf16>), grid, block, 0, st, (const bf16 *)raw,
-                           (const bf16 *)skip, (bf16 *)out, C1, C2, h, w, upsample, elu);
+                           (const bf16 *)skip, bias, (bf16 *)out, C1, C2, h, w, upsample, elu);
     else if (in_dtype == MDX_BF16 && out_dtype == MDX_F32)
         hipLaunchKernelGGL((decoder_glue_fwd_kernel<bf16, float>), grid, block, 0, st, (const bf16 *)raw,
-                           (const bf16 *)skip, (float *)out, C1, C2, h, w, upsample, elu);
+                           (const bf16 *)skip, bias, (float *)out, C1, C2, h, w, upsample, elu);
     else
         return MDX_ERR_BAD_SHAPE;
     return check_launch();
 }
 
-MDX_EXPORT int mdx_decoder_glue_bwd(const void *gout, const void *raw, void *graw, void *gskip, int B, int C1, int C2,
-                                    int h, int w, int upsample, int elu, int in_dtype, int out_dtype, void *stream)
+MDX_EXPORT size_t mdx_decoder_glue_workspace_bytes(int B, int C1, int h, int w)
+{
+    if (B <= 0 || C1 <= 0 || h <= 0 || w <= 0) return 0;
+    return (size_t)B * C1 * ((w + GX - 1) / GX) * ((h + GY * RPT - 1) / (GY * RPT)) * sizeof(float);
+}
+
+MDX_EXPORT int mdx_decoder_glue_bwd(const void *gout, const void *raw, const float *bias, void *graw, void *gskip,
+                                    float *dbias, int B, int C1, int C2, int h, int w, int upsample, int elu,
+                                    int in_dtype, int out_dtype, void *workspace, size_t workspace_bytes, void *stream)
 {
     if (!gout || !raw || !graw || (C2 > 0 && !gskip)) return MDX_ERR_NULL_POINTER;
+    if (dbias && (!workspace || workspace_bytes < mdx_decoder_glue_workspace_bytes(B, C1, h, w))) return MDX_ERR_WORKSPACE;
+    float *bias_part = dbias ? (float *)workspace : nullptr;
     const int u = upsample ? 2 : 1;
     if (B <= 0 || C1 <= 0 || C2 < 0 || h <= 0 || w <= 0 || h * u < 2 || w * u < 2 || (long long)B * (C1 + C2) > 65535)
         return MDX_ERR_BAD_SHAPE;
@@ -244,7 +291,7 @@ MDX_EXPORT int mdx_decoder_glue_bwd(const void *gout, const void *raw, void *gra
 #define MDX_GLUE_BWD(TI, TO)                                                                                          \
     do {                                                                                                              \
         hipLaunchKernelGGL((decoder_glue_bwd_raw_kernel<TI, TO>), graw_grid, block, 0, st, (const TO *)gout,          \
-                           (const TI *)raw, (TI *)graw, C1, C2, h, w, upsample, elu);                                  \
+                           (const TI *)raw, bias, (TI *)graw, bias_part, C1, C2, h, w, upsample, elu);                 \
         if (C2 > 0)                                                                                                   \
             hipLaunchKernelGGL((decoder_glue_bwd_skip_kernel<TI, TO>), gskip_grid, block, 0, st, (const TO *)gout,    \
                                (TI *)gskip, C1, C2, h * u, w * u);                                                     \
@@ -254,6 +301,9 @@ MDX_EXPORT int mdx_decoder_glue_bwd(const void *gout, const void *raw, void *gra
     else if (in_dtype == MDX_BF16 && out_dtype == MDX_F32) MDX_GLUE_BWD(bf16, float);
     else return MDX_ERR_BAD_SHAPE;
 #undef MDX_GLUE_BWD
+    if (dbias)
+        hipLaunchKernelGGL(decoder_glue_bias_finish_kernel, dim3(C1), dim3(64), 0, st, bias_part, B, C1,
+                           (int)(graw_grid.x * graw_grid.y), dbias);
     return check_launch();
 }
 

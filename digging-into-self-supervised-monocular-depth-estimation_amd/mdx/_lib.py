@@ -48,7 +48,7 @@ SYMBOLS = {
     "mdx_min_automask_fwd": C.c_int,
     "mdx_event_create": C.c_void_p, "mdx_event_destroy": None, "mdx_event_elapsed_us": C.c_int,
     "mdx_photometric_fwd_timed": C.c_int, "mdx_photometric_bwd_timed": C.c_int,
-    "mdx_decoder_glue_fwd": C.c_int, "mdx_decoder_glue_bwd": C.c_int,
+    "mdx_decoder_glue_fwd": C.c_int, "mdx_decoder_glue_bwd": C.c_int, "mdx_decoder_glue_workspace_bytes": C.c_size_t,
     "mdx_maxpool3s2_fwd": C.c_int, "mdx_maxpool3s2_bwd": C.c_int,
     "mdx_bn_workspace_bytes": C.c_size_t, "mdx_bn_act_fwd": C.c_int, "mdx_bn_act_bwd": C.c_int,
 }

@@ -426,7 +426,7 @@ def _glue_dtype(t, what):
 
 class _DecoderGlue(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, raw, skip, elu, upsample, out_dtype):
+    def forward(ctx, raw, skip, bias, elu, upsample, out_dtype):
         raw = raw.contiguous()
         in_code = _glue_dtype(raw, "decoder_glue")
         B, C1, h, w = raw.shape
@@ -438,39 +438,54 @@ class _DecoderGlue(torch.autograd.Function):
                 raise _lib.MdxError("decoder_glue: skip %s %s does not match raw %s %s (x%d)"
                                     % (tuple(skip.shape), skip.dtype, tuple(raw.shape), raw.dtype, u))
             C2 = skip.shape[1]
+        if bias is not None:
+            bias = _f32c(bias)
+            if bias.shape != (C1,):
+                raise _lib.MdxError("decoder_glue: bias %s for %d channels" % (tuple(bias.shape), C1))
         out = torch.empty(B, C1 + C2, u * h + 2, u * w + 2, device=raw.device, dtype=out_dtype)
         check(lib().mdx_decoder_glue_fwd(ptr(raw, raw.dtype), ptr(skip, raw.dtype) if skip is not None else None,
-                                         ptr(out, out_dtype), B, C1, C2, h, w, int(upsample), int(elu), in_code,
-                                         _DTYPE_CODE[out_dtype], stream()), "mdx_decoder_glue_fwd")
-        ctx.save_for_backward(raw)
+                                         ptr(bias) if bias is not None else None, ptr(out, out_dtype), B, C1, C2, h, w,
+                                         int(upsample), int(elu), in_code, _DTYPE_CODE[out_dtype], stream()),
+              "mdx_decoder_glue_fwd")
+        ctx.save_for_backward(raw, bias)
         ctx.meta = (C2, bool(elu), bool(upsample), out_dtype)
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        (raw,) = ctx.saved_tensors
+        raw, bias = ctx.saved_tensors
         C2, elu, upsample, out_dtype = ctx.meta
         B, C1, h, w = raw.shape
         u = 2 if upsample else 1
         gout = gout.contiguous().to(out_dtype)
         graw = torch.empty_like(raw)
         gskip = torch.empty(B, C2, u * h, u * w, device=raw.device, dtype=raw.dtype) if C2 else None
-        check(lib().mdx_decoder_glue_bwd(ptr(gout, out_dtype), ptr(raw, raw.dtype), ptr(graw, raw.dtype),
-                                         ptr(gskip, raw.dtype) if C2 else None, B, C1, C2, h, w, int(upsample),
-                                         int(elu), _DTYPE_CODE[raw.dtype], _DTYPE_CODE[out_dtype], stream()),
-              "mdx_decoder_glue_bwd")
-        return graw, gskip, None, None, None
+        dbias = ws = None
+        nws = 0
+        if bias is not None:
+            dbias = torch.empty(C1, device=raw.device, dtype=torch.float32)
+            nws = lib().mdx_decoder_glue_workspace_bytes(B, C1, h, w)
+            ws = torch.empty(nws // 4 + 1, device=raw.device, dtype=torch.float32)
+        check(lib().mdx_decoder_glue_bwd(ptr(gout, out_dtype), ptr(raw, raw.dtype),
+                                         ptr(bias) if bias is not None else None, ptr(graw, raw.dtype),
+                                         ptr(gskip, raw.dtype) if C2 else None, ptr(dbias) if bias is not None else None,
+                                         B, C1, C2, h, w, int(upsample), int(elu), _DTYPE_CODE[raw.dtype],
+                                         _DTYPE_CODE[out_dtype], ptr(ws) if ws is not None else None, C.c_size_t(nws),
+                                         stream()), "mdx_decoder_glue_bwd")
+        return graw, gskip, dbias, None, None, None
 
 
-def decoder_glue(raw, skip=None, elu=True, upsample=True, out_dtype=None):
-    """ReflectionPad2d(1)(cat(nearest_x2(ELU(raw)), skip)) in one pass (reference: depth_decoder.py:44-47,96-106).
+def decoder_glue(raw, skip=None, elu=True, upsample=True, out_dtype=None, bias=None):
+    """ReflectionPad2d(1)(cat(nearest_x2(ELU(raw + bias)), skip)) in one pass (reference: depth_decoder.py:44-47,96-106).
 
     raw [B,C1,h,w] (the convolution output BEFORE its ELU), skip [B,C2,u*h,u*w] or None -> [B,C1+C2,u*h+2,u*w+2].
+    bias [C1]: the bias of the convolution that produced raw when that convolution was run without it (its add and
+    its gradient reduction then happen inside these kernels instead of in two more passes over the map).
     elu / upsample switch the two stages off (plain pad: elu=False, upsample=False).  float32 or bfloat16."""
     out_dtype = out_dtype or raw.dtype
     if skip is not None and skip.dtype != raw.dtype:
         skip = skip.to(raw.dtype)
-    return _DecoderGlue.apply(raw, skip, bool(elu), bool(upsample), out_dtype)
+    return _DecoderGlue.apply(raw, skip, bias, bool(elu), bool(upsample), out_dtype)
 
 
 class _MaxPool3s2(torch.autograd.Function):

@@ -80,21 +80,24 @@ class DepthDecoder(nn.Module):
     def _forward_glue(self, input_features):
         """Same network on the GPU with everything BETWEEN two convolutions -- ELU, nearest x2, skip concat,
         reflection pad -- as one hand-written pass (mdx.functional.decoder_glue, csrc/glue.hip): a convolution
-        here produces the pre-activation map and the next glue call applies its ELU on the way into the padded
-        input of the next convolution.  Parameters, their names and the results are those of forward()."""
+        here produces the pre-activation map WITHOUT its bias and the next glue call adds the bias and applies the
+        ELU on the way into the padded input of the next convolution (its backward also reduces d(bias)).  Parameters, their names and the results are those of forward()."""
         from mdx import functional as F
         self.outputs = {}
+
+        def conv(block, x):     # the stage convolution WITHOUT its bias: the glue call that consumes it adds it
+            return TF.conv2d(x, block.conv.conv.weight, None), block.conv.conv.bias
         padded = F.decoder_glue(input_features[-1], None, elu=False, upsample=False)
         for i in (4, 3, 2, 1, 0):
             first, second = self._stage[i]
-            raw = self.decoder[first].conv.conv(padded)
+            raw, bias = conv(self.decoder[first], padded)
             skip = input_features[i - 1] if (self.use_skips and i > 0) else None
-            raw = self.decoder[second].conv.conv(F.decoder_glue(raw, skip, elu=True, upsample=True))
-            padded = F.decoder_glue(raw, None, elu=True, upsample=False) if i > 0 else None
+            raw, bias = conv(self.decoder[second], F.decoder_glue(raw, skip, elu=True, upsample=True, bias=bias))
+            padded = F.decoder_glue(raw, None, elu=True, upsample=False, bias=bias) if i > 0 else None
             if i in self._head:
                 # head + sigmoid stay float32 under bf16 autocast: the photometric kernels consume float32
                 head_in = padded if (padded is not None and padded.dtype == torch.float32) else \
-                    F.decoder_glue(raw, None, elu=True, upsample=False, out_dtype=torch.float32)
+                    F.decoder_glue(raw, None, elu=True, upsample=False, out_dtype=torch.float32, bias=bias)
                 with torch.autocast(device_type="cuda", enabled=False):
                     self.outputs[("disp", i)] = self.sigmoid(self.decoder[self._head[i]].conv(head_in))
         return self.outputs

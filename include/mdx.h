@@ -203,14 +203,18 @@ int mdx_min_automask_fwd(const float *ident, const float *noise, const float *re
  * model_layer/depth_decoder.py:44-47,96-106 and the ResNet stem max-pool, model_layer/depth_encoder.py) ----
  * dtype codes: 0 = float32, 1 = bfloat16 (storage; arithmetic is float32). */
 
-/* out [B,C1+C2,u*h+2,u*w+2] = ReflectionPad2d(1)( cat( nearest_up_u( act(raw [B,C1,h,w]) ), skip [B,C2,u*h,u*w] ) ),
- * u = upsample ? 2 : 1, act = elu ? ELU : identity; skip may be NULL when C2 == 0.
+/* out [B,C1+C2,u*h+2,u*w+2] = ReflectionPad2d(1)( cat( nearest_up_u( act(raw [B,C1,h,w] + bias [C1]) ), skip [B,C2,u*h,u*w] ) ),
+ * u = upsample ? 2 : 1, act = elu ? ELU : identity; skip may be NULL when C2 == 0; bias (float32, may be NULL) is
+ * the bias of the convolution that produced raw, when that convolution was run without it.
  * (in_dtype, out_dtype) in {(0,0), (1,1), (1,0)}; skip has in_dtype. */
-int mdx_decoder_glue_fwd(const void *raw, const void *skip, void *out, int B, int C1, int C2, int h, int w,
-                         int upsample, int elu, int in_dtype, int out_dtype, void *stream);
-/* gout has out's shape / out_dtype; graw, gskip have the inputs' shapes / in_dtype (gskip NULL when C2 == 0). */
-int mdx_decoder_glue_bwd(const void *gout, const void *raw, void *graw, void *gskip, int B, int C1, int C2, int h,
+int mdx_decoder_glue_fwd(const void *raw, const void *skip, const float *bias, void *out, int B, int C1, int C2, int h,
                          int w, int upsample, int elu, int in_dtype, int out_dtype, void *stream);
+/* gout has out's shape / out_dtype; graw, gskip have the inputs' shapes / in_dtype (gskip NULL when C2 == 0);
+ * dbias [C1] float32 = sum of graw over (b, y, x) (NULL to skip; needs the workspace, fixed summation order). */
+size_t mdx_decoder_glue_workspace_bytes(int B, int C1, int h, int w);
+int mdx_decoder_glue_bwd(const void *gout, const void *raw, const float *bias, void *graw, void *gskip, float *dbias,
+                         int B, int C1, int C2, int h, int w, int upsample, int elu, int in_dtype, int out_dtype,
+                         void *workspace, size_t workspace_bytes, void *stream);
 
 /* MaxPool2d(3, stride 2, padding 1) on [BC,H,W] -> [BC,Ho,Wo], Ho = (H-1)/2+1; arg [BC,Ho,Wo] uint8 = window tap
  * (0..8, row-major) of the first maximum, consumed by the backward (a gather, no atomics). */

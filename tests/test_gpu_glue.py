@@ -26,10 +26,13 @@ def test_decoder_glue_matches_torch_ops(F, cfg, dtype):
     raw = torch.randn(B, C1, h, w, generator=g).to("cuda", dtype).requires_grad_(True)
     u = 2 if up else 1
     skip = torch.randn(B, C2, u * h, u * w, generator=g).to("cuda", dtype).requires_grad_(True) if C2 else None
-    out = F.decoder_glue(raw, skip, elu=elu, upsample=up)
+    bias = torch.randn(C1, generator=g).cuda().requires_grad_(True) if elu else None    # conv bias folded in
+    out = F.decoder_glue(raw, skip, elu=elu, upsample=up, bias=bias)
     raw2 = raw.detach().clone().requires_grad_(True)
     skip2 = skip.detach().clone().requires_grad_(True) if C2 else None
-    x = torch.nn.functional.elu(raw2) if elu else raw2
+    bias2 = bias.detach().clone().requires_grad_(True) if bias is not None else None
+    x = raw2 if bias is None else (raw2.float() + bias2.view(1, -1, 1, 1)).to(dtype)
+    x = torch.nn.functional.elu(x) if elu else x
     if up:
         x = torch.nn.functional.interpolate(x, scale_factor=2, mode="nearest")
     if C2:
@@ -45,6 +48,9 @@ def test_decoder_glue_matches_torch_ops(F, cfg, dtype):
     torch.testing.assert_close(raw.grad.float(), raw2.grad.float(), rtol=gtol, atol=gtol)
     if C2:
         torch.testing.assert_close(skip.grad.float(), skip2.grad.float(), rtol=gtol, atol=gtol)
+    if bias is not None:
+        scale = float(bias2.grad.abs().max()) + 1e-12
+        assert float((bias.grad - bias2.grad).abs().max()) <= (1e-4 if dtype == torch.float32 else 3e-2) * scale
 
 
 def test_decoder_glue_bf16_to_f32_head_input(F):
