@@ -96,6 +96,50 @@ def test_training_step_runs_and_learns(G):
     assert o[("automask", 0)].dtype == torch.uint8 and o[("depth", 0, 0)].shape == (2, 1, 64, 96)
 
 
+def test_training_trajectory_fused_network_kernels_vs_torch_ops(G, monkeypatch):
+    """Six optimiser steps with every hand-written network kernel on (decoder glue, max-pool, fused batch norm,
+    pose pairs in one batch) against the same six steps with the torch op sequences they replace: same losses."""
+    import importlib
+    import sys
+    sys.path.insert(0, ".")
+    bench = importlib.import_module("bench")
+    from model_tool import setting, compute
+    from model_layer.depth_encoder import BatchNorm2d
+    from model_layer.depth_decoder import DepthDecoder
+    from mdx import functional as F
+
+    def run(native):
+        with monkeypatch.context() as m:
+            if not native:
+                m.setattr(BatchNorm2d, "fused_min_elements", 1 << 60)          # torch batch_norm + add + relu
+                m.setattr(DepthDecoder, "_glue_ok", lambda self: False)         # ELU / interpolate / cat / pad ops
+                m.setattr(F, "maxpool3s2", lambda x: torch.nn.functional.max_pool2d(x, 3, 2, 1))
+            torch.manual_seed(0)
+            opt = bench.make_opt(2, height=64, width=128)
+            opt.batch_pose_pairs = native
+            opt.noise = "cpu"                      # the same noise stream in both runs
+            st, cp = setting(opt, G.DEV), compute(opt, G.DEV)
+            st.set_train()
+            inputs = bench.one_batch(st, G.DEV)
+            torch.manual_seed(1)
+            losses = []
+            for _ in range(6):
+                o = {}
+                i, o = cp.forward_depth(inputs, o, st)
+                i, o = cp.forward_pose(i, o, st)
+                i, o = cp.image2warping(i, o, st)
+                o = cp.compute_loss(i, o, st)
+                st.optim["optimizer"].zero_grad(set_to_none=True)
+                o["loss"].backward()
+                st.optim["optimizer"].step()
+                losses.append(float(o["loss"].detach()))
+            return losses
+    a, b = run(True), run(False)
+    assert all(np.isfinite(a)) and all(np.isfinite(b))
+    np.testing.assert_allclose(a[:4], b[:4], rtol=2e-4, atol=1e-6)     # float32 rounding differences only ...
+    np.testing.assert_allclose(a, b, rtol=1e-2, atol=1e-5)             # ... which Adam amplifies step by step
+
+
 def test_kitti_tree_training_and_eigen_style_evaluation(G, tmp_path):
     """N2 + N3 on a synthetic KITTI-raw tree: `setting` with dataset='kitti_mono' feeds the step; the evaluation
     protocol (reference model_test.py:61-119) runs end to end with random weights."""
