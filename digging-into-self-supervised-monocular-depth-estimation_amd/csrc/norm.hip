@@ -266,15 +266,24 @@ __device__ __forceinline__ long long small_offset(int j, int c, int C, int HW, i
 }
 
 template <typename T>
-__global__ __launch_bounds__(SB) void bn_small_fwd_kernel(const T *__restrict__ x, const T *__restrict__ res,
-                                                          const float *__restrict__ gamma, const float *__restrict__ beta,
+__global__ __launch_bounds__(SB) void bn_small_fwd_kernel(const float *__restrict__ gamma, const float *__restrict__ beta,
                                                           int C, int HW, int B, float eps, float momentum, int relu,
-                                                          T *__restrict__ y, float *__restrict__ save_mean,
-                                                          float *__restrict__ save_invstd, float *__restrict__ run_mean,
-                                                          float *__restrict__ run_var)
+                                                          T *__restrict__ y_all, float *__restrict__ save_mean_all,
+                                                          float *__restrict__ save_invstd_all, float *__restrict__ run_mean,
+                                                          float *__restrict__ run_var, const T *__restrict__ x_all,
+                                                          const T *__restrict__ res_all, int G)
 {
     __shared__ float lds[SB / 64];
     const int c = blockIdx.x, M = B * HW;
+    // G consecutive sub-batches of B images, one after the other: own statistics each, running statistics updated in
+    // order (what G calls of the module do) -- from one launch
+#pragma unroll 1
+    for (int grp = 0; grp < G; ++grp) {
+    const size_t goff = (size_t)grp * B * C * HW;
+    const T *x = x_all + goff;
+    const T *res = res_all ? res_all + goff : nullptr;
+    T *y = y_all + goff;
+    float *save_mean = save_mean_all + (size_t)grp * C, *save_invstd = save_invstd_all + (size_t)grp * C;
     long long o[SV];
     Vec4<T> v[SV];
     float a = 0.f;
@@ -321,19 +330,28 @@ __global__ __launch_bounds__(SB) void bn_small_fwd_kernel(const T *__restrict__ 
         }
         *reinterpret_cast<Vec4<T> *>(y + o[j]) = w;
     }
+    }   // grp
 }
 
 template <typename T>
-__global__ __launch_bounds__(SB) void bn_small_bwd_kernel(const T *__restrict__ dy, const T *__restrict__ y,
-                                                          const T *__restrict__ x, const float *__restrict__ gamma,
+__global__ __launch_bounds__(SB) void bn_small_bwd_kernel(const T *__restrict__ dy_all, const T *__restrict__ y_all,
+                                                          const T *__restrict__ x_all, const float *__restrict__ gamma,
                                                           const float *__restrict__ save_mean,
                                                           const float *__restrict__ save_invstd, int C, int HW, int B,
-                                                          int relu, int accum, T *__restrict__ dx, T *__restrict__ dres,
-                                                          float *__restrict__ dgamma, float *__restrict__ dbeta)
+                                                          int relu, int accum, T *__restrict__ dx_all,
+                                                          T *__restrict__ dres_all, float *__restrict__ dgamma,
+                                                          float *__restrict__ dbeta, int G)
 {
     __shared__ float lds[SB / 64];
     const int c = blockIdx.x, M = B * HW;
-    const float mean = save_mean[c], invstd = save_invstd[c];
+    float tot_a = 0.f, tot_q = 0.f;
+#pragma unroll 1
+    for (int grp = 0; grp < G; ++grp) {
+    const size_t goff = (size_t)grp * B * C * HW;
+    const T *dy = dy_all + goff, *y = y_all + goff, *x = x_all + goff;
+    T *dx = dx_all + goff;
+    T *dres = dres_all ? dres_all + goff : nullptr;
+    const float mean = save_mean[(size_t)grp * C + c], invstd = save_invstd[(size_t)grp * C + c];
     long long o[SV];
     float dz[SV][VEC], xh[SV][VEC];
     float a = 0.f, q = 0.f;
@@ -354,10 +372,8 @@ __global__ __launch_bounds__(SB) void bn_small_bwd_kernel(const T *__restrict__ 
     }
     a = block_sum_1024(a, lds);
     q = block_sum_1024(q, lds);
-    if (threadIdx.x == 0) {
-        dbeta[c] = (accum ? dbeta[c] : 0.f) + a;
-        dgamma[c] = (accum ? dgamma[c] : 0.f) + q;
-    }
+    tot_a += a;
+    tot_q += q;
     const float k0 = gamma[c] * invstd, mdz = a / (float)M, mdzx = q / (float)M;
 #pragma unroll
     for (int j = 0; j < SV; ++j) {
@@ -370,6 +386,11 @@ __global__ __launch_bounds__(SB) void bn_small_bwd_kernel(const T *__restrict__ 
         }
         *reinterpret_cast<Vec4<T> *>(dx + o[j]) = wx;
         if (dres) *reinterpret_cast<Vec4<T> *>(dres + o[j]) = wr;
+    }
+    }   // grp
+    if (threadIdx.x == 0) {
+        dbeta[c] = (accum ? dbeta[c] : 0.f) + tot_a;
+        dgamma[c] = (accum ? dgamma[c] : 0.f) + tot_q;
     }
 }
 
@@ -390,84 +411,95 @@ MDX_EXPORT size_t mdx_bn_workspace_bytes(int B, int C, int H, int W)
 // dtype: 0 float32, 1 bfloat16 (x, res, y); gamma/beta/statistics float32
 MDX_EXPORT int mdx_bn_act_fwd(const void *x, const void *res, const float *gamma, const float *beta, float *run_mean,
                               float *run_var, void *y, float *save_mean, float *save_invstd, int B, int C, int H, int W,
-                              float eps, float momentum, int relu, int dtype, void *workspace, size_t workspace_bytes,
-                              void *stream)
+                              int groups, float eps, float momentum, int relu, int dtype, void *workspace,
+                              size_t workspace_bytes, void *stream)
 {
     if (!x || !gamma || !beta || !y || !save_mean || !save_invstd || !workspace) return MDX_ERR_NULL_POINTER;
     if ((run_mean == nullptr) != (run_var == nullptr)) return MDX_ERR_NULL_POINTER;
-    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || (long long)H * W > (1ll << 30)) return MDX_ERR_BAD_SHAPE;
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || groups <= 0 || (long long)H * W > (1ll << 30)) return MDX_ERR_BAD_SHAPE;
+    if (dtype != 0 && dtype != 1) return MDX_ERR_BAD_SHAPE;
     const int HW = H * W, K = spans_per_plane(HW);
     if ((long long)B * K > 65535) return MDX_ERR_BAD_SHAPE;
     if (workspace_bytes < mdx_bn_workspace_bytes(B, C, H, W)) return MDX_ERR_WORKSPACE;
-    const dim3 grid(C, B * K), block(NB);
     hipStream_t st = (hipStream_t)stream;
-    float *part = (float *)workspace;
-    if (small_map(B, HW) && dtype <= 1) {
+    if (small_map(B, HW)) {
         if (dtype == 0)
-            hipLaunchKernelGGL((bn_small_fwd_kernel<float>), dim3(C), dim3(SB), 0, st, (const float *)x, (const float *)res,
-                               gamma, beta, C, HW, B, eps, momentum, relu, (float *)y, save_mean, save_invstd, run_mean,
-                               run_var);
+            hipLaunchKernelGGL((bn_small_fwd_kernel<float>), dim3(C), dim3(SB), 0, st, gamma, beta, C, HW, B, eps, momentum,
+                               relu, (float *)y, save_mean, save_invstd, run_mean, run_var, (const float *)x,
+                               (const float *)res, groups);
         else
-            hipLaunchKernelGGL((bn_small_fwd_kernel<bf16n>), dim3(C), dim3(SB), 0, st, (const bf16n *)x,
-                               (const bf16n *)res, gamma, beta, C, HW, B, eps, momentum, relu, (bf16n *)y, save_mean,
-                               save_invstd, run_mean, run_var);
+            hipLaunchKernelGGL((bn_small_fwd_kernel<bf16n>), dim3(C), dim3(SB), 0, st, gamma, beta, C, HW, B, eps, momentum,
+                               relu, (bf16n *)y, save_mean, save_invstd, run_mean, run_var, (const bf16n *)x,
+                               (const bf16n *)res, groups);
         return check_launch();
     }
-    if (dtype == 0) {
-        hipLaunchKernelGGL((bn_fwd_stats_kernel<float>), grid, block, 0, st, (const float *)x, C, HW, K, part);
-        hipLaunchKernelGGL((bn_fwd_apply_kernel<float>), grid, block, 0, st, (const float *)x, (const float *)res, gamma,
-                           beta, part, C, HW, K, B, eps, momentum, relu, (float *)y, save_mean, save_invstd, run_mean,
-                           run_var);
-    } else if (dtype == 1) {
-        hipLaunchKernelGGL((bn_fwd_stats_kernel<bf16n>), grid, block, 0, st, (const bf16n *)x, C, HW, K, part);
-        hipLaunchKernelGGL((bn_fwd_apply_kernel<bf16n>), grid, block, 0, st, (const bf16n *)x, (const bf16n *)res, gamma,
-                           beta, part, C, HW, K, B, eps, momentum, relu, (bf16n *)y, save_mean, save_invstd, run_mean,
-                           run_var);
-    } else {
-        return MDX_ERR_BAD_SHAPE;
+    const dim3 grid(C, B * K), block(NB);
+    float *part = (float *)workspace;
+    const size_t gelems = (size_t)B * C * HW, esize = dtype == 0 ? 4 : 2;
+    for (int g = 0; g < groups; ++g) {   // sub-batches in order (running statistics): stream order does that
+        const char *xg = (const char *)x + g * gelems * esize;
+        const char *rg = res ? (const char *)res + g * gelems * esize : nullptr;
+        char *yg = (char *)y + g * gelems * esize;
+        float *sm = save_mean + (size_t)g * C, *si = save_invstd + (size_t)g * C;
+        if (dtype == 0) {
+            hipLaunchKernelGGL((bn_fwd_stats_kernel<float>), grid, block, 0, st, (const float *)xg, C, HW, K, part);
+            hipLaunchKernelGGL((bn_fwd_apply_kernel<float>), grid, block, 0, st, (const float *)xg, (const float *)rg, gamma,
+                               beta, part, C, HW, K, B, eps, momentum, relu, (float *)yg, sm, si, run_mean, run_var);
+        } else {
+            hipLaunchKernelGGL((bn_fwd_stats_kernel<bf16n>), grid, block, 0, st, (const bf16n *)xg, C, HW, K, part);
+            hipLaunchKernelGGL((bn_fwd_apply_kernel<bf16n>), grid, block, 0, st, (const bf16n *)xg, (const bf16n *)rg, gamma,
+                               beta, part, C, HW, K, B, eps, momentum, relu, (bf16n *)yg, sm, si, run_mean, run_var);
+        }
     }
     return check_launch();
 }
 
 MDX_EXPORT int mdx_bn_act_bwd(const void *dy, const void *y, const void *x, const float *gamma, const float *save_mean,
                               const float *save_invstd, void *dx, void *dres, float *dgamma, float *dbeta, int B, int C,
-                              int H, int W, int relu, int accumulate, int dtype, void *workspace, size_t workspace_bytes,
+                              int H, int W, int groups, int relu, int dtype, void *workspace, size_t workspace_bytes,
                               void *stream)
 {
     if (!dy || !y || !x || !gamma || !save_mean || !save_invstd || !dx || !dgamma || !dbeta || !workspace)
         return MDX_ERR_NULL_POINTER;
-    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || (long long)H * W > (1ll << 30)) return MDX_ERR_BAD_SHAPE;
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || groups <= 0 || (long long)H * W > (1ll << 30)) return MDX_ERR_BAD_SHAPE;
+    if (dtype != 0 && dtype != 1) return MDX_ERR_BAD_SHAPE;
     const int HW = H * W, K = spans_per_plane(HW);
     if ((long long)B * K > 65535) return MDX_ERR_BAD_SHAPE;
     if (workspace_bytes < mdx_bn_workspace_bytes(B, C, H, W)) return MDX_ERR_WORKSPACE;
-    const dim3 grid(C, B * K), block(NB);
     hipStream_t st = (hipStream_t)stream;
-    float *part = (float *)workspace;
-    if (small_map(B, HW) && dtype <= 1) {
+    if (small_map(B, HW)) {
         if (dtype == 0)
             hipLaunchKernelGGL((bn_small_bwd_kernel<float>), dim3(C), dim3(SB), 0, st, (const float *)dy, (const float *)y,
-                               (const float *)x, gamma, save_mean, save_invstd, C, HW, B, relu, accumulate, (float *)dx,
-                               (float *)dres, dgamma, dbeta);
+                               (const float *)x, gamma, save_mean, save_invstd, C, HW, B, relu, 0, (float *)dx,
+                               (float *)dres, dgamma, dbeta, groups);
         else
             hipLaunchKernelGGL((bn_small_bwd_kernel<bf16n>), dim3(C), dim3(SB), 0, st, (const bf16n *)dy, (const bf16n *)y,
-                               (const bf16n *)x, gamma, save_mean, save_invstd, C, HW, B, relu, accumulate, (bf16n *)dx,
-                               (bf16n *)dres, dgamma, dbeta);
+                               (const bf16n *)x, gamma, save_mean, save_invstd, C, HW, B, relu, 0, (bf16n *)dx,
+                               (bf16n *)dres, dgamma, dbeta, groups);
         return check_launch();
     }
-    if (dtype == 0) {
-        hipLaunchKernelGGL((bn_bwd_stats_kernel<float>), grid, block, 0, st, (const float *)dy, (const float *)y,
-                           (const float *)x, save_mean, save_invstd, C, HW, K, relu, part);
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), grid, block, 0, st, (const float *)dy, (const float *)y,
-                           (const float *)x, gamma, save_mean, save_invstd, part, C, HW, K, B, relu, accumulate, (float *)dx,
-                           (float *)dres, dgamma, dbeta);
-    } else if (dtype == 1) {
-        hipLaunchKernelGGL((bn_bwd_stats_kernel<bf16n>), grid, block, 0, st, (const bf16n *)dy, (const bf16n *)y,
-                           (const bf16n *)x, save_mean, save_invstd, C, HW, K, relu, part);
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16n>), grid, block, 0, st, (const bf16n *)dy, (const bf16n *)y,
-                           (const bf16n *)x, gamma, save_mean, save_invstd, part, C, HW, K, B, relu, accumulate, (bf16n *)dx,
-                           (bf16n *)dres, dgamma, dbeta);
-    } else {
-        return MDX_ERR_BAD_SHAPE;
+    const dim3 grid(C, B * K), block(NB);
+    float *part = (float *)workspace;
+    const size_t gelems = (size_t)B * C * HW, esize = dtype == 0 ? 4 : 2;
+    for (int g = 0; g < groups; ++g) {
+        const char *dyg = (const char *)dy + g * gelems * esize, *yg = (const char *)y + g * gelems * esize;
+        const char *xg = (const char *)x + g * gelems * esize;
+        char *dxg = (char *)dx + g * gelems * esize;
+        char *drg = dres ? (char *)dres + g * gelems * esize : nullptr;
+        const float *sm = save_mean + (size_t)g * C, *si = save_invstd + (size_t)g * C;
+        if (dtype == 0) {
+            hipLaunchKernelGGL((bn_bwd_stats_kernel<float>), grid, block, 0, st, (const float *)dyg, (const float *)yg,
+                               (const float *)xg, sm, si, C, HW, K, relu, part);
+            hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), grid, block, 0, st, (const float *)dyg, (const float *)yg,
+                               (const float *)xg, gamma, sm, si, part, C, HW, K, B, relu, g > 0, (float *)dxg,
+                               (float *)drg, dgamma, dbeta);
+        } else {
+            hipLaunchKernelGGL((bn_bwd_stats_kernel<bf16n>), grid, block, 0, st, (const bf16n *)dyg, (const bf16n *)yg,
+                               (const bf16n *)xg, sm, si, C, HW, K, relu, part);
+            hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16n>), grid, block, 0, st, (const bf16n *)dyg, (const bf16n *)yg,
+                               (const bf16n *)xg, gamma, sm, si, part, C, HW, K, B, relu, g > 0, (bf16n *)dxg,
+                               (bf16n *)drg, dgamma, dbeta);
+        }
     }
     return check_launch();
 }

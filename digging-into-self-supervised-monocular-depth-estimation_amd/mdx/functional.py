@@ -545,14 +545,12 @@ class _BnAct(torch.autograd.Function):
         Bg = B // groups
         nws = lib().mdx_bn_workspace_bytes(Bg, Cc, H, W)
         ws = torch.empty(nws // 4 + 1, device=x.device, dtype=torch.float32)
-        for g in range(groups):
-            sl = slice(g * Bg, (g + 1) * Bg)
-            check(lib().mdx_bn_act_fwd(
-                ptr(x[sl], x.dtype), ptr(res[sl], x.dtype) if res is not None else None, ptr(weight), ptr(bias),
-                ptr(running_mean) if running_mean is not None else None,
-                ptr(running_var) if running_var is not None else None, ptr(y[sl], x.dtype), ptr(save_mean[g]),
-                ptr(save_invstd[g]), Bg, Cc, H, W, C.c_float(eps), C.c_float(momentum), int(relu), code, ptr(ws),
-                C.c_size_t(nws), stream()), "mdx_bn_act_fwd")
+        check(lib().mdx_bn_act_fwd(
+            ptr(x, x.dtype), ptr(res, x.dtype) if res is not None else None, ptr(weight), ptr(bias),
+            ptr(running_mean) if running_mean is not None else None,
+            ptr(running_var) if running_var is not None else None, ptr(y, x.dtype), ptr(save_mean), ptr(save_invstd),
+            Bg, Cc, H, W, groups, C.c_float(eps), C.c_float(momentum), int(relu), code, ptr(ws), C.c_size_t(nws),
+            stream()), "mdx_bn_act_fwd")
         ctx.save_for_backward(x, y, weight, save_mean, save_invstd)
         ctx.meta = (bool(relu), res is not None, groups)
         ctx.mark_non_differentiable(*[t for t in (running_mean, running_var) if t is not None])
@@ -571,13 +569,10 @@ class _BnAct(torch.autograd.Function):
         dbeta = torch.empty(Cc, device=x.device, dtype=torch.float32)
         nws = lib().mdx_bn_workspace_bytes(Bg, Cc, H, W)
         ws = torch.empty(nws // 4 + 1, device=x.device, dtype=torch.float32)
-        for g in range(groups):
-            sl = slice(g * Bg, (g + 1) * Bg)
-            check(lib().mdx_bn_act_bwd(
-                ptr(dy[sl], x.dtype), ptr(y[sl], x.dtype), ptr(x[sl], x.dtype), ptr(weight), ptr(save_mean[g]),
-                ptr(save_invstd[g]), ptr(dx[sl], x.dtype), ptr(dres[sl], x.dtype) if has_res else None, ptr(dgamma),
-                ptr(dbeta), Bg, Cc, H, W, int(relu), int(g > 0), _DTYPE_CODE[x.dtype], ptr(ws), C.c_size_t(nws),
-                stream()), "mdx_bn_act_bwd")
+        check(lib().mdx_bn_act_bwd(
+            ptr(dy, x.dtype), ptr(y, x.dtype), ptr(x, x.dtype), ptr(weight), ptr(save_mean), ptr(save_invstd),
+            ptr(dx, x.dtype), ptr(dres, x.dtype) if has_res else None, ptr(dgamma), ptr(dbeta), Bg, Cc, H, W, groups,
+            int(relu), _DTYPE_CODE[x.dtype], ptr(ws), C.c_size_t(nws), stream()), "mdx_bn_act_bwd")
         return dx, dres, dgamma, dbeta, None, None, None, None, None, None
 
 

@@ -224,18 +224,21 @@ int mdx_maxpool3s2_bwd(const void *gout, const uint8_t *arg, void *gin, int BC, 
 /* Training-mode BatchNorm2d + residual add + ReLU of the ResNet blocks (model_layer/depth_encoder.py; the reference
  * gets them from torchvision): y = act(bn(x) [+ res]) with batch statistics over (B,H,W), running statistics updated
  * in place as torch.nn.functional.batch_norm(training=True) does (run_mean/run_var may both be NULL).
- * x, res, y, dy, dx, dres: [B,C,H,W] float32 (dtype 0) or bfloat16 (dtype 1); gamma, beta, statistics float32.
- * save_mean / save_invstd [C] go from forward to backward.  Two launches each way (statistics pass, apply pass). */
+ * The tensors hold `groups` consecutive sub-batches of B images: x, res, y, dy, dx, dres [groups*B,C,H,W] float32
+ * (dtype 0) or bfloat16 (dtype 1); each sub-batch is normalised with its own statistics and updates the running
+ * statistics in turn -- what `groups` calls on the sub-batches do.  gamma, beta, statistics float32;
+ * save_mean / save_invstd [groups,C] go from forward to backward.  One launch each way for maps up to 24 K elements
+ * per channel and sub-batch, two per sub-batch above. */
 size_t mdx_bn_workspace_bytes(int B, int C, int H, int W);
 int mdx_bn_act_fwd(const void *x, const void *res, const float *gamma, const float *beta, float *run_mean,
                    float *run_var, void *y, float *save_mean, float *save_invstd, int B, int C, int H, int W,
-                   float eps, float momentum, int relu, int dtype, void *workspace, size_t workspace_bytes,
+                   int groups, float eps, float momentum, int relu, int dtype, void *workspace, size_t workspace_bytes,
                    void *stream);
-/* dz = dy * (y > 0) when relu; dx, d(res) = dz (dres NULL when there was no residual), dgamma, dbeta [C]
- * (accumulate != 0: added to what dgamma / dbeta hold -- a batch processed as several sub-batches). */
+/* dz = dy * (y > 0) when relu; dx, d(res) = dz (dres NULL when there was no residual); dgamma, dbeta [C] summed
+ * over the sub-batches. */
 int mdx_bn_act_bwd(const void *dy, const void *y, const void *x, const float *gamma, const float *save_mean,
                    const float *save_invstd, void *dx, void *dres, float *dgamma, float *dbeta, int B, int C, int H,
-                   int W, int relu, int accumulate, int dtype, void *workspace, size_t workspace_bytes, void *stream);
+                   int W, int groups, int relu, int dtype, void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }
