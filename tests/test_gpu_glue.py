@@ -234,3 +234,33 @@ def test_batched_pose_pairs_equal_the_loop_on_gpu():
                 continue
             err, scale = float((p.grad - q.grad).norm()), float(q.grad.norm())
             assert err <= 2e-2 * scale + 1e-6, "%s.%s: %g vs %g" % (name, n, err, scale)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(6, 8, 12, 40), (4, 16, 96, 320)])      # single-launch path, two-pass path
+def test_bn_act_groups_equal_separate_calls(F, shape, dtype):
+    """bn_act(groups=2) on a batch == bn_act on its two halves one after the other (outputs, running statistics,
+    gradients): what lets both frame pairs go through the pose network in one batch."""
+    B, Cc, H, W = shape
+    g = torch.Generator().manual_seed(3)
+    x0 = torch.randn(B, Cc, H, W, generator=g).to("cuda", dtype)
+    r0 = torch.randn(B, Cc, H, W, generator=g).to("cuda", dtype)
+    w0, b0 = (torch.rand(Cc, generator=g) + 0.5).cuda(), torch.randn(Cc, generator=g).cuda()
+    gy = torch.randn(B, Cc, H, W, generator=g).to("cuda", dtype)
+    out = {}
+    for mode in ("grouped", "separate"):
+        x, r = x0.clone().requires_grad_(True), r0.clone().requires_grad_(True)
+        w, b = w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        rm, rv = torch.zeros(Cc, device="cuda"), torch.ones(Cc, device="cuda")
+        if mode == "grouped":
+            y = F.bn_act(x, w, b, rm, rv, 1e-5, 0.1, residual=r, relu=True, groups=2)
+        else:
+            y = torch.cat([F.bn_act(xc, w, b, rm, rv, 1e-5, 0.1, residual=rc, relu=True)
+                           for xc, rc in zip(x.chunk(2), r.chunk(2))])
+        y.backward(gy)
+        out[mode] = (y.detach(), rm, rv, x.grad, r.grad, w.grad, b.grad)
+    for a, bb, name in zip(out["grouped"], out["separate"], ("y", "running_mean", "running_var", "dx", "dres", "dgamma", "dbeta")):
+        if name in ("dgamma", "dbeta"):      # summed in the kernel vs by autograd: same terms, different order
+            torch.testing.assert_close(a, bb, rtol=1e-4 if dtype == torch.float32 else 2e-2, atol=1e-3, msg=name)
+        else:
+            assert torch.equal(a, bb), name
