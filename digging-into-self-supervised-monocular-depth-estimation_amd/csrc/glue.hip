@@ -195,6 +195,51 @@ __global__ __launch_bounds__(GX *GY) void maxpool3s2_fwd_kernel(const T *__restr
     arg[o] = (uint8_t)bi;
 }
 
+// W % 4 == 0 variant: one thread per TWO adjacent outputs (xo = 2j, 2j+1).  Their windows span input columns
+// 4j-1 .. 4j+3: per row one aligned 4-element load plus one scalar, instead of six scalar loads.
+// grid: (ceil(Wo/2/64), ceil(Ho/4), B*C)
+template <typename T> struct __attribute__((aligned(sizeof(T) * 4))) Quad { T v[4]; };
+template <typename T> struct __attribute__((aligned(sizeof(T) * 2))) Pair { T v[2]; };
+
+template <typename T>
+__global__ __launch_bounds__(GX *GY) void maxpool3s2_fwd2_kernel(const T *__restrict__ in, T *__restrict__ out,
+                                                                  uint8_t *__restrict__ arg, int H, int W, int Ho, int Wo)
+{
+    const int j = blockIdx.x * GX + threadIdx.x, yo = blockIdx.y * GY + threadIdx.y;
+    if (2 * j >= Wo || yo >= Ho) return;
+    const T *p = in + (size_t)blockIdx.z * H * W;
+    float row[3][5];
+    bool rok[3];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int y = 2 * yo - 1 + ky;
+        rok[ky] = y >= 0 && y < H;
+        const size_t base = (size_t)(rok[ky] ? y : 0) * W + 4 * j;
+        const Quad<T> q = *reinterpret_cast<const Quad<T> *>(p + base);
+        row[ky][0] = j > 0 ? to_float(p[base - 1]) : 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) row[ky][1 + k] = to_float(q.v[k]);
+    }
+    float best[2] = {-INFINITY, -INFINITY};
+    int bi[2] = {-1, -1};
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int ky = k / 3, kx = k % 3;
+            if (!rok[ky] || (o == 0 && kx == 0 && j == 0)) continue;       // outside the image
+            const float v = row[ky][2 * o + kx];
+            if (bi[o] < 0) bi[o] = k;
+            if (v > best[o] || v != v) { best[o] = v; bi[o] = k; }
+        }
+    const size_t oo = ((size_t)blockIdx.z * Ho + yo) * Wo + 2 * j;
+    Pair<T> pv;
+    pv.v[0] = from_float<T>(best[0]);
+    pv.v[1] = from_float<T>(best[1]);
+    *reinterpret_cast<Pair<T> *>(out + oo) = pv;
+    *reinterpret_cast<uint16_t *>(arg + oo) = (uint16_t)(bi[0] | (bi[1] << 8));
+}
+
 // One thread per 2x2 input block (rows 2*yo, 2*yo+1; columns 2*xo, 2*xo+1): only the four windows (yo..yo+1,
 // xo..xo+1) can have selected one of its pixels, so four index bytes and four gradients serve four outputs.
 // grid: (ceil(ceil(W/2)/64), ceil(ceil(H/2)/4), B*C)
@@ -313,14 +358,23 @@ MDX_EXPORT int mdx_maxpool3s2_fwd(const void *in, void *out, uint8_t *arg, int B
     if (BC <= 0 || BC > 65535 || H <= 0 || W <= 0) return MDX_ERR_BAD_SHAPE;
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;   // floor((H + 2 - 3) / 2) + 1
     const dim3 grid = grid3(Wo, Ho, BC), block(GX, GY);
+    if (dtype != MDX_F32 && dtype != MDX_BF16) return MDX_ERR_BAD_SHAPE;
+    if (W % 4 == 0) {      // rows 16-byte (8-byte for bf16) aligned, Wo even: two outputs per thread
+        const dim3 grid2 = grid3(Wo / 2, Ho, BC);
+        if (dtype == MDX_F32)
+            hipLaunchKernelGGL((maxpool3s2_fwd2_kernel<float>), grid2, block, 0, (hipStream_t)stream, (const float *)in,
+                               (float *)out, arg, H, W, Ho, Wo);
+        else
+            hipLaunchKernelGGL((maxpool3s2_fwd2_kernel<bf16>), grid2, block, 0, (hipStream_t)stream, (const bf16 *)in,
+                               (bf16 *)out, arg, H, W, Ho, Wo);
+        return check_launch();
+    }
     if (dtype == MDX_F32)
         hipLaunchKernelGGL((maxpool3s2_fwd_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float *)in,
                            (float *)out, arg, H, W, Ho, Wo);
-    else if (dtype == MDX_BF16)
+    else
         hipLaunchKernelGGL((maxpool3s2_fwd_kernel<bf16>), grid, block, 0, (hipStream_t)stream, (const bf16 *)in,
                            (bf16 *)out, arg, H, W, Ho, Wo);
-    else
-        return MDX_ERR_BAD_SHAPE;
     return check_launch();
 }
 
