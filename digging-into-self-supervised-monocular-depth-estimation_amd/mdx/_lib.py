@@ -51,6 +51,7 @@ SYMBOLS = {
     "mdx_decoder_glue_fwd": C.c_int, "mdx_decoder_glue_bwd": C.c_int, "mdx_decoder_glue_workspace_bytes": C.c_size_t,
     "mdx_maxpool3s2_fwd": C.c_int, "mdx_maxpool3s2_bwd": C.c_int,
     "mdx_bn_workspace_bytes": C.c_size_t, "mdx_bn_act_fwd": C.c_int, "mdx_bn_act_bwd": C.c_int,
+    "mdx_param2matrix_fwd": C.c_int, "mdx_param2matrix_bwd": C.c_int,
 }
 
 

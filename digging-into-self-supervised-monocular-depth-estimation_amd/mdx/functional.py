@@ -583,3 +583,34 @@ def bn_act(x, weight, bias, running_mean, running_var, eps=1e-5, momentum=0.1, r
     groups: number of consecutive sub-batches normalised independently (see _BnAct)."""
     return _BnAct.apply(x, residual, weight, bias, running_mean, running_var, float(eps), float(momentum), bool(relu),
                         int(groups))
+
+
+# ---- param2matrix (csrc/pose.hip) ----------------------------------------------------------------------------------
+class _Param2Matrix(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, axisangle, translation, invert):
+        aa, tr = _f32c(axisangle).reshape(-1, 3), _f32c(translation).reshape(-1, 3)
+        N = aa.shape[0]
+        if tr.shape[0] != N:
+            raise _lib.MdxError("param2matrix: %d rotations, %d translations" % (N, tr.shape[0]))
+        M = torch.empty(N, 4, 4, device=aa.device, dtype=torch.float32)
+        check(lib().mdx_param2matrix_fwd(ptr(aa), ptr(tr), N, int(invert), ptr(M), stream()), "mdx_param2matrix_fwd")
+        ctx.save_for_backward(aa, tr)
+        ctx.meta = (bool(invert), axisangle.shape, translation.shape)
+        return M
+
+    @staticmethod
+    def backward(ctx, gM):
+        aa, tr = ctx.saved_tensors
+        invert, sa, st = ctx.meta
+        gM = _f32c(gM)
+        gaa, gtr = torch.empty_like(aa), torch.empty_like(tr)
+        check(lib().mdx_param2matrix_bwd(ptr(aa), ptr(tr), ptr(gM), aa.shape[0], int(invert), ptr(gaa), ptr(gtr),
+                                         stream()), "mdx_param2matrix_bwd")
+        return gaa.reshape(sa), gtr.reshape(st), None
+
+
+def param2matrix(axisangle, translation, invert=False):
+    """(axis-angle [N,1,3], translation [N,1,3]) -> camera-to-camera matrix [N,4,4] (reference warp.py:126-153) in
+    one launch; backward by forward-mode differentiation inside the kernel."""
+    return _Param2Matrix.apply(axisangle, translation, bool(invert))

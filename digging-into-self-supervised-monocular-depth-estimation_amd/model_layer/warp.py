@@ -83,7 +83,10 @@ def angle2rotation(anlge_axis):
 
 
 def param2matrix(axisangle, translation, invert=False):
-    """reference: model_layer/warp.py:126-153.  axisangle, translation [N,1,3] -> [N,4,4]."""
+    """reference: model_layer/warp.py:126-153.  axisangle, translation [N,1,3] -> [N,4,4].
+    float32 GPU tensors: one kernel each way (csrc/pose.hip) instead of ~40 element-wise ops; else the torch ops."""
+    if axisangle.is_cuda and axisangle.dtype == torch.float32 and translation.dtype == torch.float32:
+        return F.param2matrix(axisangle, translation, invert)
     R = angle2rotation(axisangle)
     t = translation.clone()
     if invert:

@@ -199,6 +199,13 @@ int mdx_min_automask_fwd(const float *ident, const float *noise, const float *re
                          int H, int W, int automask, float *combined, float *to_opt, uint8_t *idx,
                          void *stream);
 
+/* param2matrix   model_layer/warp.py:126-153 (with vector2translation :43-61, angle2rotation :65-122).
+ * axisangle, translation [N,3] (the reference's [N,1,3]) -> M [N,4,4]; invert as in the reference.
+ * bwd: gM [N,4,4] -> gaxisangle, gtranslation [N,3]. */
+int mdx_param2matrix_fwd(const float *axisangle, const float *translation, int N, int invert, float *M, void *stream);
+int mdx_param2matrix_bwd(const float *axisangle, const float *translation, const float *gM, int N, int invert,
+                         float *gaxisangle, float *gtranslation, void *stream);
+
 /* ---- network glue around the convolutions (no reference FFI: these replace torch op sequences of
  * model_layer/depth_decoder.py:44-47,96-106 and the ResNet stem max-pool, model_layer/depth_encoder.py) ----
  * dtype codes: 0 = float32, 1 = bfloat16 (storage; arithmetic is float32). */

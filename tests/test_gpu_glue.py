@@ -264,3 +264,32 @@ def test_bn_act_groups_equal_separate_calls(F, shape, dtype):
             torch.testing.assert_close(a, bb, rtol=1e-4 if dtype == torch.float32 else 2e-2, atol=1e-3, msg=name)
         else:
             assert torch.equal(a, bb), name
+
+
+@pytest.mark.parametrize("invert", [False, True])
+def test_param2matrix_kernel_matches_torch_ops(F, invert):
+    """mdx_param2matrix == the reference's op sequence (vector2translation / angle2rotation / matmul), forward and
+    backward, incl. tiny angles (the 1e-5 in the normalisation) and the exact zero rotation."""
+    from model_layer.warp import angle2rotation, vector2translation
+    g = torch.Generator().manual_seed(2)
+    aa0 = torch.randn(9, 1, 3, generator=g) * torch.tensor([1.0, 0.3, 0.01, 1e-3, 1e-5, 2.5, 0.0, 0.7, 3.0]).view(9, 1, 1)
+    t0 = torch.randn(9, 1, 3, generator=g)
+    gm = torch.randn(9, 4, 4, generator=g).cuda()
+
+    def ref(aa, t):
+        R = angle2rotation(aa)
+        tt = t.clone()
+        if invert:
+            R, tt = R.transpose(1, 2), tt * -1
+        T = vector2translation(tt)
+        return torch.matmul(R, T) if invert else torch.matmul(T, R)
+    a1, t1 = aa0.cuda().requires_grad_(True), t0.cuda().requires_grad_(True)
+    a2, t2 = aa0.double().requires_grad_(True), t0.double().requires_grad_(True)
+    M1, M2 = F.param2matrix(a1, t1, invert), ref(a2, t2)
+    torch.testing.assert_close(M1.double().cpu(), M2, rtol=2e-6, atol=2e-6)
+    M1.backward(gm)
+    M2.backward(gm.double().cpu())
+    torch.testing.assert_close(t1.grad.double().cpu(), t2.grad, rtol=1e-5, atol=1e-5)
+    ok = aa0.abs().sum((1, 2)) > 0                     # at the exact origin |a| has no gradient: both give a finite value
+    torch.testing.assert_close(a1.grad.double().cpu()[ok], a2.grad[ok], rtol=2e-4, atol=2e-4)
+    assert torch.isfinite(a1.grad).all()
