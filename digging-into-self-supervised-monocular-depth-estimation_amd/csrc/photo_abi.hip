@@ -96,7 +96,7 @@ __global__ __launch_bounds__(NT) void upsample_bwd_kernel(const float *__restric
     gin[i] = acc;
 }
 
-static int launch_upsample_bwd(const float *gout, int BC, int H, int W, float *gin, int h, int w, hipStream_t st)
+int launch_upsample_bwd(const float *gout, int BC, int H, int W, float *gin, int h, int w, hipStream_t st)
 {
     const size_t n = (size_t)BC * h * w;
     const int foot = (int)ceilf(2.0f * (float)W / (float)w) + 3;

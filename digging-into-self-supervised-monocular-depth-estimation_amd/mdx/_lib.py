@@ -12,6 +12,7 @@ import torch
 LIB_PATH = os.environ.get("MDX_LIB") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                                                      "libmdx_hip.so")   # MDX_LIB: developer override (kernel A/B builds)
 MAX_SRC = 4
+MAX_SCALES = 4
 FLAG_AUTOMASK = 1
 _lib = None
 
@@ -27,6 +28,12 @@ class Desc(C.Structure):
 
 class Sources(C.Structure):
     _fields_ = [("img", C.c_void_p * MAX_SRC)]
+
+
+class TrainDesc(C.Structure):   # mdx_train_desc
+    _fields_ = [("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("S", C.c_int32), ("nscales", C.c_int32),
+                ("flags", C.c_uint32), ("disp_a", C.c_float), ("disp_b", C.c_float),
+                ("h", C.c_int32 * MAX_SCALES), ("w", C.c_int32 * MAX_SCALES), ("rows_per_chunk", C.c_int32)]
 
 
 class Timing(C.Structure):   # mdx_timing: hipEvent_t pair recorded right before / after the fused kernel
@@ -52,6 +59,8 @@ SYMBOLS = {
     "mdx_maxpool3s2_fwd": C.c_int, "mdx_maxpool3s2_bwd": C.c_int,
     "mdx_bn_workspace_bytes": C.c_size_t, "mdx_bn_act_fwd": C.c_int, "mdx_bn_act_bwd": C.c_int,
     "mdx_param2matrix_fwd": C.c_int, "mdx_param2matrix_bwd": C.c_int,
+    "mdx_train_desc_init": C.c_int, "mdx_photometric_train_workspace_bytes": C.c_size_t,
+    "mdx_photometric_train": C.c_int,
 }
 
 
@@ -112,6 +121,28 @@ def make_desc(B, H, W, h, w, S, automask, min_depth, max_depth):
     check(lib().mdx_desc_init(C.byref(d), B, H, W, h, w, S, int(bool(automask)), C.c_double(min_depth),
                               C.c_double(max_depth)), "mdx_desc_init")
     return d
+
+
+def make_train_desc(B, H, W, S, hw, automask, min_depth, max_depth, rows_per_chunk=0):
+    """hw: [(h_s, w_s)] per scale."""
+    if not 1 <= len(hw) <= MAX_SCALES:
+        raise MdxError("1..%d scales supported, got %d" % (MAX_SCALES, len(hw)))
+    d = TrainDesc()
+    hs = (C.c_int32 * len(hw))(*[int(x[0]) for x in hw])
+    ws = (C.c_int32 * len(hw))(*[int(x[1]) for x in hw])
+    check(lib().mdx_train_desc_init(C.byref(d), B, H, W, S, len(hw), hs, ws, int(bool(automask)),
+                                    C.c_double(min_depth), C.c_double(max_depth), int(rows_per_chunk)),
+          "mdx_train_desc_init")
+    return d
+
+
+def ptr_array(tensors, dtype=torch.float32, optional=False):
+    """Host array of device pointers (one per scale); None entries allowed when optional."""
+    arr = (C.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        p = ptr(t, dtype, optional=optional)
+        arr[i] = p.value if p is not None else None
+    return arr
 
 
 def make_sources(tensors):

@@ -77,7 +77,7 @@ def _timing_hook(kind):
     if TIMING is None:
         return None
     t = _lib.Timing(lib().mdx_event_create(), lib().mdx_event_create())
-    TIMING[kind].append(t)
+    TIMING.setdefault(kind, []).append(t)
     return t
 
 
@@ -184,6 +184,78 @@ def photometric_scale(disp, P, target, sources, invK, ident=None, noise=None, au
                save_warp=save_warp, save_coef=save_coef)
     out = _PhotometricScale.apply(disp, P, target, invK, ident, noise, cfg, *sources)
     return dict(zip(("sum", "idx", "to_opt", "depth", "warp", "reproj"), out))
+
+
+class _PhotometricTrain(torch.autograd.Function):
+    """All scales, forward and gradient, in one launch (csrc/photo_train.hip).  Returns (sums [nscales], idx_0..,
+    depth0 or None, to_opt_0.. or None); keeps only the unit-upstream gradients for backward."""
+
+    @staticmethod
+    def forward(ctx, P, target, invK, ident, cfg, noises, sources, *disps):
+        nsc = len(disps)
+        disps = [_f32c(x) for x in disps]
+        target, invK = _f32c(target), _f32c(invK)
+        sources = [_f32c(x) for x in sources]
+        per_scale_P = isinstance(P, (list, tuple))
+        Ps = [_f32c(x) for x in P] if per_scale_P else [_f32c(P)] * nsc
+        B, _, H, W = target.shape
+        S = len(sources)
+        automask = cfg["automask"]
+        dev = target.device
+        d = _lib.make_train_desc(B, H, W, S, [tuple(x.shape[2:]) for x in disps], automask, cfg["min_depth"],
+                                 cfg["max_depth"], cfg.get("rows_per_chunk", 0))
+        src = _lib.make_sources(sources)
+        if automask:
+            ident = _f32c(ident)
+            noises = [_f32c(x) for x in noises]
+        idx = [torch.empty(B, H, W, device=dev, dtype=torch.uint8) for _ in range(nsc)]
+        sums = torch.empty(nsc, device=dev, dtype=torch.float32)
+        gdisp = [torch.empty_like(x) for x in disps]
+        gP = torch.empty(nsc, S, B, 3, 4, device=dev, dtype=torch.float32)
+        depth0 = torch.empty(B, 1, H, W, device=dev, dtype=torch.float32) if cfg.get("need_depth") else None
+        to_opt = [torch.empty(B, H, W, device=dev, dtype=torch.float32) for _ in range(nsc)] \
+            if cfg.get("need_to_opt") else None
+        nws = lib().mdx_photometric_train_workspace_bytes(C.byref(d))
+        ws = torch.empty(nws // 16 + 1, 2, dtype=torch.float64, device=dev)
+        hook = _timing_hook("train")
+        check(lib().mdx_photometric_train(
+            C.byref(d), _lib.ptr_array(disps), ptr(target), C.byref(src), ptr(invK), _lib.ptr_array(Ps),
+            ptr(ident) if automask else None, _lib.ptr_array(noises) if automask else None,
+            _lib.ptr_array(idx, torch.uint8), ptr(sums), _lib.ptr_array(gdisp), ptr(gP), ptr(depth0, optional=True),
+            _lib.ptr_array(to_opt) if to_opt is not None else None, ptr(ws, torch.float64), C.c_size_t(nws), stream(),
+            C.byref(hook) if hook is not None else None), "mdx_photometric_train")
+        ctx.save_for_backward(gP, *gdisp)
+        ctx.per_scale_P = per_scale_P
+        extras = idx + [depth0] + (to_opt if to_opt is not None else [])
+        ctx.mark_non_differentiable(*[t for t in extras if t is not None])
+        return (sums, *idx, depth0, *(to_opt if to_opt is not None else []))
+
+    @staticmethod
+    def backward(ctx, g_sums, *_unused):
+        gP, *gdisp = ctx.saved_tensors
+        g = g_sums.float()
+        gPs = gP * g.view(-1, 1, 1, 1, 1)
+        gP_out = [gPs[s] for s in range(gP.shape[0])] if ctx.per_scale_P else gPs.sum(0)
+        return (gP_out, None, None, None, None, None, None) + tuple(gd * g[s] for s, gd in enumerate(gdisp))
+
+
+def photometric_train(disps, P, target, sources, invK, ident=None, noises=None, automask=True, min_depth=0.1,
+                      max_depth=100.0, need_depth=False, need_to_opt=False, rows_per_chunk=0):
+    """The training step's photometric term for every scale at once: forward and gradient in one launch.
+
+    disps: list of [B,1,h_s,w_s] (grad); P [S,B,3,4] (grad; shared by the scales);
+    noises: list of [B,S,H,W] (automask).  Returns dict: 'sums' [nscales] (differentiable: sum over pixels of
+    to_optimise per scale), 'idx' (list of uint8 [B,H,W]), 'depth' (scale 0, optional), 'to_opt' (optional list)."""
+    if isinstance(P, (list, tuple)):
+        raise _lib.MdxError("photometric_train: scale-dependent projections (posecnn) take the per-scale path")
+    cfg = dict(automask=bool(automask), min_depth=float(min_depth), max_depth=float(max_depth),
+               need_depth=bool(need_depth), need_to_opt=bool(need_to_opt), rows_per_chunk=int(rows_per_chunk))
+    n = len(disps)
+    out = _PhotometricTrain.apply(P, target, invK, ident, cfg, list(noises) if noises is not None else None,
+                                  list(sources), *disps)
+    res = dict(sums=out[0], idx=list(out[1:1 + n]), depth=out[1 + n])
+    res["to_opt"] = list(out[2 + n:2 + 2 * n]) if need_to_opt else None
+    return res
 
 
 class _SmoothLoss(torch.autograd.Function):

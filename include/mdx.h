@@ -30,8 +30,9 @@
 extern "C" {
 #endif
 
-#define MDX_VERSION 100
+#define MDX_VERSION 200
 #define MDX_MAX_SRC 4
+#define MDX_MAX_SCALES 4
 
 typedef enum mdx_status {
     MDX_OK = 0,
@@ -137,6 +138,40 @@ int mdx_photometric_bwd_timed(const mdx_desc *d, const float *disp, const float 
                         const uint8_t *idx, const float *warp, const float *coef, float g_const,
                         const float *g_dev, float *gdisp, float *gP, void *workspace, size_t workspace_bytes,
                         void *stream, const mdx_timing *t);
+
+/* ------------------------------------------------------------------------------------------
+ * Training step: every scale, forward AND gradient, in one launch
+ *   replaces the scale loops of processor.py:140-163 and :167-204,212 plus their autograd backward.
+ * Everything downstream of sum(to_optimise) is linear in the upstream gradient, so the kernel returns the
+ * gradients for a UNIT upstream: d loss / d disp_s = g_s * gdisp[s], d loss / d P = sum_s g_s * gP[s]
+ * where g_s = d loss / d loss_sum[s] (the caller's autograd multiplies; nothing else is kept for backward).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct mdx_train_desc {
+    int32_t B, H, W;                 /* images, full resolution */
+    int32_t S;                       /* source frames, 1..MDX_MAX_SRC */
+    int32_t nscales;                 /* len(opt.scales), 1..MDX_MAX_SCALES */
+    uint32_t flags;                  /* as mdx_desc.flags */
+    float disp_a, disp_b;            /* as mdx_desc */
+    int32_t h[MDX_MAX_SCALES], w[MDX_MAX_SCALES];   /* outputs[("disp", s)] is [B,1,h[s],w[s]] */
+    int32_t rows_per_chunk;          /* rows one wave walks; 0 = chosen by the library */
+} mdx_train_desc;
+
+int mdx_train_desc_init(mdx_train_desc *d, int B, int H, int W, int S, int nscales, const int32_t *h,
+                        const int32_t *w, int automask, double min_depth, double max_depth, int rows_per_chunk);
+size_t mdx_photometric_train_workspace_bytes(const mdx_train_desc *d);
+
+/* disp, P, noise, idx, gdisp, to_opt: HOST arrays of nscales DEVICE pointers.
+ *   disp[s] [B,1,h[s],w[s]]; P[s] [S,B,3,4] (the same pointer for every scale unless the pose depends on the
+ *   scale); noise[s], ident [B,S,H,W] (MDX_FLAG_AUTOMASK only); target [B,3,H,W]; invK [B,4,4].
+ * Outputs: idx[s] [B,H,W] uint8; loss_sum [nscales]; gdisp[s] [B,1,h[s],w[s]]; gP [nscales,S,B,3,4];
+ *   optional depth0 [B,1,H,W] (depth of scale 0, outputs[("depth",0,0)]); optional to_opt (array may be NULL,
+ *   entries may be NULL) [B,H,W].
+ * t (optional): events recorded right before / after the fused kernel. */
+int mdx_photometric_train(const mdx_train_desc *d, const float *const *disp, const float *target,
+                          const mdx_sources *src, const float *invK, const float *const *P, const float *ident,
+                          const float *const *noise, uint8_t *const *idx, float *loss_sum, float *const *gdisp,
+                          float *gP, float *depth0, float *const *to_opt, void *workspace, size_t workspace_bytes,
+                          void *stream, const mdx_timing *t);
 
 /* Edge-aware smoothness   replaces model_loss.py:77-88,112-115 (processor.py:208).
  * disp [B,1,h,w], color [B,3,h,w] -> loss [1]; gdisp (optional) = d loss / d disp for unit upstream.

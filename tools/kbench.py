@@ -2,7 +2,11 @@
 """Kernel micro-benchmark: launches only the hand-written photometric kernels (B=12, 192x640, S=2, the
 BASELINE configs[1] shape) so that rocprofv3 --kernel-trace / --pmc sees nothing else.
 
-    python tools/kbench.py [--reps 20] [--B 12] [--S 2] [--what fwd,bwd,ident,smooth]
+    python tools/kbench.py [--reps 20] [--B 12] [--S 2] [--what fwd,bwd,ident,smooth,train] [--rows 0]
+
+`train` = mdx_photometric_train: all scales, forward and gradient, one launch (csrc/photo_train.hip); its fused
+kernel is timed by the HIP events the *_timed hook records around it, the whole call (with the finishing pass and the
+upsample transposes) by events around the call.
 """
 import argparse
 import ctypes as C
@@ -27,7 +31,9 @@ def main():
     ap.add_argument("--H", type=int, default=192)
     ap.add_argument("--W", type=int, default=640)
     ap.add_argument("--S", type=int, default=2)
-    ap.add_argument("--what", type=str, default="fwd,bwd,ident,smooth")
+    ap.add_argument("--what", type=str, default="fwd,bwd,ident,smooth,train")
+    ap.add_argument("--rows", type=int, default=0, help="rows per chunk of the training kernel (0 = library default)")
+    ap.add_argument("--nscales", type=int, default=4)
     ap.add_argument("--save_warp", type=int, default=2,
                     help="0: backward re-warps; 1: forward stores the warp; 2: SSIM coefficient maps only (training form); 3: both")
     a = ap.parse_args()
@@ -54,12 +60,14 @@ def main():
     src = _lib.make_sources(srcs)
     what = a.what.split(",")
     ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
+    all_disps = []
     for s in range(4):
         h, w = H >> s, W >> s
         # network-like disparity: smooth field (low-res noise, bilinearly upsampled) through a sigmoid
         lo = torch.randn(B, 1, max(H // 32, 2), max(W // 32, 2), generator=g)
         disp = torch.sigmoid(torch.nn.functional.interpolate(lo, size=(h, w), mode="bilinear",
                                                              align_corners=False)).contiguous().to(dev)
+        all_disps.append(disp)
         warp = torch.empty(S, B, 3, H, W, device=dev)
         coef = torch.empty(B, 9, H, W, device=dev)
         color_s = torch.nn.functional.avg_pool2d(tgt, 2 ** s) if s else tgt
@@ -96,9 +104,9 @@ def main():
         fns = {"fwd": fwd, "bwd": bwd, "ident": ident_fn, "smooth": smooth}
         out = []
         for name in what:
-            fn = fns[name]
-            if name == "ident" and s:
+            if name == "train" or (name == "ident" and s):
                 continue
+            fn = fns[name]
             for _ in range(3):
                 fn()
             e0, e1 = ev(), ev()
@@ -109,6 +117,47 @@ def main():
             e1.synchronize()
             out.append("%s %.1f us" % (name, 1e3 * e0.elapsed_time(e1) / a.reps))
         print("scale %d: %s  (masked %.1f%%)" % (s, ", ".join(out), 100.0 * float((idx < S).float().mean())), flush=True)
+
+    if "train" in what:
+        nsc = a.nscales
+        disps = all_disps[:nsc]
+        noises = [torch.randn(B, S, H, W, generator=g).to(dev) for _ in range(nsc)]
+        td = _lib.make_train_desc(B, H, W, S, [tuple(x.shape[2:]) for x in disps], True, 0.1, 100.0, a.rows)
+        idxs = [torch.empty(B, H, W, dtype=torch.uint8, device=dev) for _ in range(nsc)]
+        sums = torch.empty(nsc, device=dev)
+        gdisps = [torch.empty_like(x) for x in disps]
+        gPs = torch.empty(nsc, S, B, 3, 4, device=dev)
+        nws = lib.mdx_photometric_train_workspace_bytes(C.byref(td))
+        ws = torch.empty(nws // 16 + 1, 2, dtype=torch.float64, device=dev)
+        pd, pP, pn = _lib.ptr_array(disps), _lib.ptr_array([P] * nsc), _lib.ptr_array(noises)
+        pi, pg = _lib.ptr_array(idxs, torch.uint8), _lib.ptr_array(gdisps)
+
+        def train(hook=None):
+            _lib.check(lib.mdx_photometric_train(
+                C.byref(td), pd, _lib.ptr(tgt), C.byref(src), _lib.ptr(invK), pP, _lib.ptr(ident), pn, pi,
+                _lib.ptr(sums), pg, _lib.ptr(gPs), None, None, _lib.ptr(ws, torch.float64), C.c_size_t(nws),
+                _lib.stream(), C.byref(hook) if hook is not None else None), "train")
+        for _ in range(3):
+            train()
+        e0, e1 = ev(), ev()
+        e0.record()
+        for _ in range(a.reps):
+            train()
+        e1.record()
+        e1.synchronize()
+        hooks = [_lib.Timing(lib.mdx_event_create(), lib.mdx_event_create()) for _ in range(a.reps)]
+        for hk in hooks:
+            train(hk)
+        torch.cuda.synchronize()
+        us = []
+        for hk in hooks:
+            v = C.c_float()
+            _lib.check(lib.mdx_event_elapsed_us(C.c_void_p(hk.start), C.c_void_p(hk.stop), C.byref(v)), "elapsed")
+            us.append(v.value)
+        masked = [100.0 * float((i < S).float().mean()) for i in idxs]
+        print("train (%d scales, rows/chunk %d): whole call %.1f us, fused kernel %.1f us (min %.1f)  masked %s"
+              % (nsc, a.rows, 1e3 * e0.elapsed_time(e1) / a.reps, sum(us) / len(us), min(us),
+                 " ".join("%.1f%%" % m for m in masked)), flush=True)
 
 
 if __name__ == "__main__":
