@@ -16,6 +16,9 @@ LIB = os.path.join(HERE, "libmdx_hip.so")
 SOURCES = ["photo_fwd.hip", "photo_bwd.hip", "photo_train.hip", "photo_abi.hip", "smooth.hip", "ops.hip", "glue.hip", "norm.hip", "pose.hip"]
 HEADERS = ["mdx_device.hpp", "mdx_common.hpp", "photo_common.hpp", "mdx_divtable.inc", os.path.join("..", "..", "include", "mdx.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# per-file additions.  photo_train.hip: the SLP vectorizer pairs neighbouring f32 ops into v_pk_* (no faster per element
+# on gfx950, profiles/r02_micro_valu_rate.txt) at the price of register pairs, packing moves and un-folded DPP operands
+EXTRA_FLAGS = {"photo_train.hip": ["-fno-slp-vectorize"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 
@@ -34,7 +37,7 @@ def build(force=False, verbose=False):
     procs = []
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
-        cmd = [HIPCC] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [HIPCC] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -41,7 +41,23 @@ struct TrainArgs {
     float *depth0;
     double *loss_part;   // [items]
     float *partP;        // [items][S][12]
+    unsigned long long *stamps;   // diagnostic builds (-DMDX_TRAIN_STAMPS) only: [items][8] phase cycle sums
 };
+
+// In-kernel phase clock of the diagnostic build (cdna_hip_programming.md section 7, "In-kernel stamps"): the values go to a
+// buffer of their own and no output is computed from them; the product build compiles none of it.
+#ifdef MDX_TRAIN_STAMPS
+#define MDX_STAMP(k)                                                         \
+    do {                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                   \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();        \
+        st_acc[k] += now_ - st_last;                                         \
+        st_last = now_;                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                   \
+    } while (0)
+#else
+#define MDX_STAMP(k) do { } while (0)
+#endif
 
 // wave-uniform selection from a by-value kernel-argument array without dynamic indexing (which would send the
 // argument block to scratch)
@@ -59,23 +75,84 @@ template <int CTRL> MDX_DEV int dpp_i(int v) { return __builtin_amdgcn_update_dp
 MDX_DEV float from_left(float v) { return dpp_f<0x138>(v); }    // wave_shr:1
 MDX_DEV float from_right(float v) { return dpp_f<0x130>(v); }   // wave_shl:1
 
-// AvgPool2d(3,1) at this lane's column over history rows (a0, a1, a2): the nine taps summed row-major,
-// sequentially, then a true divide by 9 -- pool9()'s order with the side columns taken from the neighbour lanes.
-MDX_DEV float pool3(float a0, float a1, float a2)
+// AvgPool2d(3,1) at this lane's column for N independent quantities at once; a[i][j] = quantity i at history row j.
+// Per quantity the nine taps are summed row-major, sequentially, then truly divided by 9 -- pool9()'s order, with
+// the side columns read from the neighbour lanes.  The N chains advance in lock step: a DPP instruction that reads a
+// register written by one of the two preceding VALU instructions costs wait states (s_nop), and a VALU instruction
+// that consumes its predecessor's result issues at half rate (profiles/r02_micro_valu_dep.txt); with N >= 3 chains
+// interleaved neither happens.
+template <int N> MDX_DEV void pool3_n(const float (&a)[N][3], float (&out)[N])
 {
-    float s = from_left(a0) + a0;
-    s = s + from_right(a0);
-    s = s + from_left(a1);
-    s = s + a1;
-    s = s + from_right(a1);
-    s = s + from_left(a2);
-    s = s + a2;
-    s = s + from_right(a2);
-    return div9(s);
+    float s[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) s[i] = from_left(a[i][0]) + a[i][0];
+#pragma unroll
+    for (int i = 0; i < N; ++i) s[i] = s[i] + from_right(a[i][0]);
+#pragma unroll
+    for (int j = 1; j < 3; ++j) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) s[i] = s[i] + from_left(a[i][j]);
+#pragma unroll
+        for (int i = 0; i < N; ++i) s[i] = s[i] + a[i][j];
+#pragma unroll
+        for (int i = 0; i < N; ++i) s[i] = s[i] + from_right(a[i][j]);
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) out[i] = div9(s[i]);
+}
+
+// SSIM of one colour channel of one frame, value AND gradient coefficients in one go.  The value follows ssim_raw()
+// operation for operation (bit-exact); the coefficient triplet of SURVEY appendix A.1 re-uses its intermediates and a
+// hardware reciprocal (gradients carry a 1e-4 tolerance, not bit-exactness).
+struct SsimBoth { float val; SsimGrad g; };
+
+MDX_DEV SsimBoth ssim_both(const SsimTerms &s, const TargetStats &t, float gscale)
+{
+    const float mxx = s.mu_x * s.mu_x;
+    const float mxy = s.mu_x * t.mu;
+    const float sig_x = s.ex2 - mxx;
+    const float sig_y = t.e2 - t.mu2;
+    const float sig_xy = s.exy - mxy;
+    float a = 2.0f * s.mu_x;
+    a = a * t.mu;
+    const float A1 = a + MDX_C1;
+    float A2 = 2.0f * sig_xy;
+    A2 = A2 + MDX_C2;
+    const float n = A1 * A2;
+    const float B1 = (mxx + t.mu2) + MDX_C1;
+    const float B2 = (sig_x + sig_y) + MDX_C2;
+    const float d = B1 * B2;
+    const float q = n / d;
+    const float raw = (1.0f - q) / 2.0f;
+    SsimBoth r;
+    r.val = clamp01(raw);
+#ifndef MDX_TRAIN_RCP
+#define MDX_TRAIN_RCP 1
+#endif
+#if MDX_TRAIN_RCP == 0
+    const float inv_d = __builtin_amdgcn_rcpf(d);
+#elif MDX_TRAIN_RCP == 1
+    float inv_d = __builtin_amdgcn_rcpf(d);                              // 1 ulp
+    inv_d = __builtin_fmaf(__builtin_fmaf(-d, inv_d, 1.0f), inv_d, inv_d);   // one Newton step
+#else
+    const float inv_d = 1.0f / d;
+#endif
+#if MDX_TRAIN_RCP == 3
+    const float Ln = -0.5f * inv_d, Ld = 0.5f * n * inv_d * inv_d;
+#else
+    const float Ln = -0.5f * inv_d, Ld = 0.5f * q * inv_d;
+#endif
+    const float dA1 = Ln * A2, dA2 = Ln * A1, dB1 = Ld * B2, dB2 = Ld * B1;
+    const bool pass = raw >= 0.f && raw <= 1.f;   // clamp passes the gradient on the closed interval
+    const float gs = pass ? gscale : 0.f;
+    r.g.alpha = gs * 2.0f * (t.mu * (dA1 - dA2) + s.mu_x * (dB1 - dB2));
+    r.g.beta = gs * dB2;
+    r.g.gamma = gs * 2.0f * dA2;
+    return r;
 }
 
 template <int S>
-__global__ __launch_bounds__(64) void photometric_train_kernel(TrainArgs a)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S <= 2 ? 3 : 2, S <= 2 ? 3 : 2))) void photometric_train_kernel(TrainArgs a)
 {
     // per-lane stash ring: [row slot][2f] = (d colour_c / du, u), [2f+1] = (d colour_c / dv, v) of frame f
     __shared__ float4 s_stash[3][2 * S][64];
@@ -124,16 +201,29 @@ __global__ __launch_bounds__(64) void photometric_train_kernel(TrainArgs a)
 
     const int r0 = chunk * a.rows, r1 = min(r0 + a.rows, H);
 
+    // ---- the item's matrices, once, as wave-uniform scalars (inside the loop they would be re-fetched through vector
+    //      memory every row and consumed at once: two exposed cache round trips per row) ----
+    float Pm[S][12], iK[12];
+#pragma unroll
+    for (int f = 0; f < S; ++f)
+#pragma unroll
+        for (int k = 0; k < 12; ++k)
+            Pm[f][k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(
+                __builtin_bit_cast(int, P_s[((size_t)f * d.B + b) * 12 + k])));
+#pragma unroll
+    for (int k = 0; k < 12; ++k)
+        iK[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, invK_b[k])));
+
     // ---- histories (registers) ----
     float xh[3][S][3];   // warped colours, rows wr-2 .. wr
     float yh[3][3];      // target colours, same rows
     float ch[3][3][3];   // [row][channel][alpha,beta,gamma] of the arg-min frame, rows sr-2 .. sr
-    int selh[3];         // arg-min frame (or -1), same rows
-    int flh[3];          // grid_sample pass flags (bit 2f: x inside, 2f+1: y inside), rows wr-2 .. wr
+    int selp = 0;        // arg-min frame + 1 (0 = none) of rows sr-2, sr-1, sr in bits 0-3, 4-7, 8-11
+    int flp = 0;         // grid_sample pass flags (bit 2f: x inside, 2f+1: y inside) of rows wr-2, wr-1, wr in bytes 0-2
     float dph[3];        // depth, rows wr-2 .. wr
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        selh[j] = -1; flh[j] = 0; dph[j] = 0.f;
+        dph[j] = 0.f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             yh[j][c] = 0.f;
@@ -143,13 +233,48 @@ __global__ __launch_bounds__(64) void photometric_train_kernel(TrainArgs a)
             for (int k = 0; k < 3; ++k) ch[j][c][k] = 0.f;
         }
     }
-    float accP[S][12];
+    // d(P) accumulators.  With X_j = depth * r_j and the pixel ray r = invK (px, py, 1) linear in the pixel, the twelve
+    // sums of a frame follow from nine: A_i = sum gq_i*depth, Bv_i = sum py*gq_i*depth, C_i = sum gq_i (px is a
+    // constant of the lane and is applied at the end).
+    float accA[S][3], accB[S][3], accC[S][3];
 #pragma unroll
     for (int f = 0; f < S; ++f)
 #pragma unroll
-        for (int k = 0; k < 12; ++k) accP[f][k] = 0.f;
+        for (int i = 0; i < 3; ++i) accA[f][i] = accB[f][i] = accC[f][i] = 0.f;
     double acc = 0.0;
 
+    // ---- prefetch registers: the loads of the NEXT step whose addresses do not depend on computed data ----
+    float pf_y[3], pf_d[4], pf_id[S], pf_nz[S];
+    auto prefetch_warp_row = [&](int wr) {      // target colours + disparity taps of row wr
+        const int pyr = reflect(min(max(wr, -1), H), H);
+        const unsigned po = (unsigned)(pyr * W + pxr);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) pf_y[c] = at32(tgt_b + c * HW, po);
+        if (same_res) {
+            pf_d[0] = at32(disp_b, po);
+        } else {
+            const UpTap ty = up_tap((float)d.h / (float)H, pyr, d.h);
+            const float *row0 = disp_b + ty.i0 * d.w, *row1 = disp_b + ty.i1 * d.w;
+            pf_d[0] = row0[tx.i0]; pf_d[1] = row0[tx.i1]; pf_d[2] = row1[tx.i0]; pf_d[3] = row1[tx.i1];
+        }
+    };
+    auto prefetch_ssim_row = [&](int sr) {      // identity loss + noise of row sr
+        if (!automask) return;
+        const unsigned po = (unsigned)(min(max(sr, 0), H - 1) * W + pxr);
+#pragma unroll
+        for (int f = 0; f < S; ++f) {
+            pf_id[f] = at32(a.ident + ((size_t)b * S + f) * HW, po);
+            pf_nz[f] = at32(noise_s + ((size_t)b * S + f) * HW, po);
+        }
+    };
+    prefetch_warp_row(r0 - 2);
+    prefetch_ssim_row(r0 - 3);
+
+#ifdef MDX_TRAIN_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_last = __builtin_amdgcn_s_memtime();
+    const unsigned long long st_begin = st_last;
+#endif
     const int nsteps = (r1 - r0) + 4;
 #pragma unroll 1
     for (int t = 0; t < nsteps; ++t) {
@@ -165,208 +290,268 @@ __global__ __launch_bounds__(64) void photometric_train_kernel(TrainArgs a)
 #pragma unroll
             for (int f = 0; f < S; ++f) { xh[0][f][c] = xh[1][f][c]; xh[1][f][c] = xh[2][f][c]; }
         }
-        flh[0] = flh[1]; flh[1] = flh[2];
+        flp = (unsigned)flp >> 8;
         dph[0] = dph[1]; dph[1] = dph[2];
-        if (wr >= -1 && wr <= H) {
-            const int pyr = reflect(wr, H);
-            const unsigned po = (unsigned)(pyr * W + pxr);
+        {   // rows beyond the reflected ring (only the first step of a chunk at the image's top, the last at its
+            // bottom) are warped at the clamped row and never used: no branch, one code path for the memory counters
+            const int pyr = reflect(min(max(wr, -1), H), H);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) yh[2][c] = at32(tgt_b + c * HW, po);
+            for (int c = 0; c < 3; ++c) yh[2][c] = pf_y[c];
             float up;
             if (same_res) {
-                up = at32(disp_b, po);
+                up = pf_d[0];
             } else {
                 const UpTap ty = up_tap((float)d.h / (float)H, pyr, d.h);
-                const float *row0 = disp_b + ty.i0 * d.w, *row1 = disp_b + ty.i1 * d.w;
-                up = up_combine(row0[tx.i0], row0[tx.i1], row1[tx.i0], row1[tx.i1], ty, tx, premul);
+                up = up_combine(pf_d[0], pf_d[1], pf_d[2], pf_d[3], ty, tx, premul);
             }
-            const PixelGeom g = geom_from_disp(d, up, invK_b, pxr, pyr);
+            const PixelGeom g = geom_from_disp(d, up, iK, pxr, pyr);
             dph[2] = g.depth;
-            if (a.depth0 && scale == 0 && out_lane && wr >= r0 && wr < r1) at32(a.depth0 + (size_t)b * HW, po) = g.depth;
+            if (a.depth0 && scale == 0 && out_lane && wr >= r0 && wr < r1)
+                at32(a.depth0 + (size_t)b * HW, (unsigned)(pyr * W + pxr)) = g.depth;
+            // taps of every frame first, then ALL corner loads, then (while they fly) the next step's prefetches
+            Proj pr[S];
+            Tap tp[S];
+            Corners cn[S][3];
+#pragma unroll
+            for (int f = 0; f < S; ++f) {
+                pr[f] = project_point(Pm[f], g.X0, g.X1, g.X2, 1.0f, nd, 1e-7f);
+                tp[f] = make_tap(pr[f].gx, pr[f].gy, H, W);
+            }
+#pragma unroll
+            for (int f = 0; f < S; ++f)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    cn[f][c] = load_corners(a.src.img[f] + ((size_t)b * 3 + c) * HW, H, W, tp[f]);
+            prefetch_warp_row(wr + 1);
+            MDX_STAMP(0);   // geometry, taps, load issue
             int fl = 0;
 #pragma unroll
             for (int f = 0; f < S; ++f) {
-                const float *Pf = P_s + ((size_t)f * d.B + b) * 12;
-                const Proj pr = project_point(Pf, g.X0, g.X1, g.X2, 1.0f, nd, 1e-7f);
-                const Tap tp = make_tap(pr.gx, pr.gy, H, W);
-                const float *src_b = a.src.img[f] + (size_t)b * 3 * HW;
-                Corners cn[3];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) cn[c] = load_corners(src_b + c * HW, H, W, tp);
-                const float dy1 = (float)(tp.y0 + 1) - tp.iy, dy0 = tp.iy - (float)tp.y0;
-                const float dx1 = (float)(tp.x0 + 1) - tp.ix, dx0 = tp.ix - (float)tp.x0;
+                const float dy1 = (float)(tp[f].y0 + 1) - tp[f].iy, dy0 = tp[f].iy - (float)tp[f].y0;
+                const float dx1 = (float)(tp[f].x0 + 1) - tp[f].ix, dx0 = tp[f].ix - (float)tp[f].x0;
                 float du[3], dv[3];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    xh[2][f][c] = sample(cn[c], tp);
-                    du[c] = (cn[c].ne - cn[c].nw) * dy1 + (cn[c].se - cn[c].sw) * dy0;
-                    dv[c] = (cn[c].sw - cn[c].nw) * dx1 + (cn[c].se - cn[c].ne) * dx0;
+                    xh[2][f][c] = sample(cn[f][c], tp[f]);
+                    du[c] = (cn[f][c].ne - cn[f][c].nw) * dy1 + (cn[f][c].se - cn[f][c].sw) * dy0;
+                    dv[c] = (cn[f][c].sw - cn[f][c].nw) * dx1 + (cn[f][c].se - cn[f][c].ne) * dx0;
                 }
-                s_stash[slot_w][2 * f][lane] = make_float4(du[0], du[1], du[2], pr.u);
-                s_stash[slot_w][2 * f + 1][lane] = make_float4(dv[0], dv[1], dv[2], pr.v);
-                fl |= (tp.inx ? 1 : 0) << (2 * f);
-                fl |= (tp.iny ? 1 : 0) << (2 * f + 1);
+                s_stash[slot_w][2 * f][lane] = make_float4(du[0], du[1], du[2], pr[f].u);
+                s_stash[slot_w][2 * f + 1][lane] = make_float4(dv[0], dv[1], dv[2], pr[f].v);
+                fl |= (tp[f].inx ? 1 : 0) << (2 * f);
+                fl |= (tp[f].iny ? 1 : 0) << (2 * f + 1);
             }
-            flh[2] = fl;
+            flp |= fl << 16;
+            MDX_STAMP(1);   // corner data arrives, samples, derivatives, stash
         }
 
         // ================= (2) SSIM + L1, min / arg-min, coefficient triplets of row sr =================
-        if (t < 2) continue;
-        selh[0] = selh[1]; selh[1] = selh[2];
+        selp = (unsigned)selp >> 4;
 #pragma unroll
         for (int c = 0; c < 3; ++c)
 #pragma unroll
             for (int k = 0; k < 3; ++k) { ch[0][c][k] = ch[1][c][k]; ch[1][c][k] = ch[2][c][k]; }
-        if (sr >= 0 && sr < H) {
-            const unsigned po = (unsigned)(sr * W + pxr);
-            float idv[S], nzv[S];
-            if (automask) {
-#pragma unroll
-                for (int f = 0; f < S; ++f) {
-                    idv[f] = at32(a.ident + ((size_t)b * S + f) * HW, po);
-                    nzv[f] = at32(noise_s + ((size_t)b * S + f) * HW, po);
-                }
-            }
+        if (t >= 2 && sr >= 0 && sr < H) {
+            // every product a pool reads through DPP is formed in a block of its own, pinned ahead of the pools by a
+            // scheduling barrier (see pool3_n); three chains at a time keep the transient registers low
             TargetStats ts[3];
+            {
+                float q[3][3], o[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float y0 = yh[0][c], y1 = yh[1][c], y2 = yh[2][c];
-                ts[c].mu = pool3(y0, y1, y2);
-                ts[c].e2 = pool3(y0 * y0, y1 * y1, y2 * y2);
-                ts[c].mu2 = ts[c].mu * ts[c].mu;
+                for (int c = 0; c < 3; ++c)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) q[c][j] = yh[j][c];
+                pool3_n<3>(q, o);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { ts[c].mu = o[c]; ts[c].mu2 = o[c] * o[c]; }
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) q[c][j] = yh[j][c] * yh[j][c];
+                __builtin_amdgcn_sched_barrier(0);
+                pool3_n<3>(q, o);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) ts[c].e2 = o[c];
             }
-            float rl[S];
-            SsimTerms st[S][3];
+            // reprojection channels in order; the coefficient triplets of the best reprojection frame so far are
+            // kept as the candidate (strict <: torch.min's first-minimum rule among equal values)
+            float best_r = 0.f;
+            int fr = 0;
+            float cand[3][3];
 #pragma unroll
             for (int f = 0; f < S; ++f) {
                 float ss[3], ad[3];
+                SsimGrad sg[3];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    const float x0 = xh[0][f][c], x1 = xh[1][f][c], x2 = xh[2][f][c];
-                    st[f][c].mu_x = pool3(x0, x1, x2);
-                    st[f][c].ex2 = pool3(x0 * x0, x1 * x1, x2 * x2);
-                    st[f][c].exy = pool3(x0 * yh[0][c], x1 * yh[1][c], x2 * yh[2][c]);
-                    ss[c] = clamp01(ssim_raw(st[f][c], ts[c]));
-                    ad[c] = fabsf(yh[1][c] - x1);
+                    float q[3][3], o[3];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        q[0][j] = xh[j][f][c];
+                        q[1][j] = xh[j][f][c] * xh[j][f][c];
+                        q[2][j] = xh[j][f][c] * yh[j][c];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    pool3_n<3>(q, o);
+                    SsimTerms st;
+                    st.mu_x = o[0]; st.ex2 = o[1]; st.exy = o[2];
+                    const SsimBoth sb = ssim_both(st, ts[c], 0.85f / 3.0f);
+                    ss[c] = sb.val;
+                    sg[c] = sb.g;
+                    ad[c] = fabsf(yh[1][c] - xh[1][f][c]);
                 }
-                rl[f] = reprojection_combine(ss, ad);
+                const float rl = reprojection_combine(ss, ad);
+                const bool better = f == 0 || rl < best_r;
+                best_r = better ? rl : best_r;
+                fr = better ? f : fr;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    cand[c][0] = better ? sg[c].alpha : cand[c][0];
+                    cand[c][1] = better ? sg[c].beta : cand[c][1];
+                    cand[c][2] = better ? sg[c].gamma : cand[c][2];
+                }
             }
             // concat [ident + 1e-5*noise, reproj] and torch.min's first-minimum rule (processor.py:194-204)
-            float best = 0.f;
-            int bi = 0;
+            float best = best_r;
+            int bi = fr;
             if (automask) {
+                float bid = 0.f;
+                int fi = 0;
 #pragma unroll
                 for (int f = 0; f < S; ++f) {
-                    const float tn = 1e-5f * nzv[f];
-                    const float v = idv[f] + tn;
-                    if (f == 0 || v < best) { best = v; bi = f; }
+                    const float tn = 1e-5f * pf_nz[f];
+                    const float v = pf_id[f] + tn;
+                    if (f == 0 || v < bid) { bid = v; fi = f; }
                 }
-#pragma unroll
-                for (int f = 0; f < S; ++f)
-                    if (rl[f] < best) { best = rl[f]; bi = S + f; }
-            } else {
-                best = rl[0];
-#pragma unroll
-                for (int f = 1; f < S; ++f)
-                    if (rl[f] < best) { best = rl[f]; bi = f; }
+                const bool reproj_wins = best_r < bid;     // identity channels come first: ties go to them
+                best = reproj_wins ? best_r : bid;
+                bi = reproj_wins ? S + fr : fi;
+                fr = reproj_wins ? fr : -1;
             }
-            int fsel = automask ? bi - S : bi;
-            if (!ssim_lane) fsel = -1;
+            if (!ssim_lane) fr = -1;
+            const bool keep = fr >= 0;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                SsimTerms sel = st[0][c];
+            for (int c = 0; c < 3; ++c)
 #pragma unroll
-                for (int f = 1; f < S; ++f)
-                    if (fsel == f) sel = st[f][c];
-                SsimGrad sg = ssim_grad(sel, ts[c], 0.85f / 3.0f);
-                const bool keep = fsel >= 0;
-                ch[2][c][0] = keep ? sg.alpha : 0.f;
-                ch[2][c][1] = keep ? sg.beta : 0.f;
-                ch[2][c][2] = keep ? sg.gamma : 0.f;
-            }
-            selh[2] = fsel;
+                for (int k = 0; k < 3; ++k) ch[2][c][k] = keep ? cand[c][k] : 0.f;
+            selp |= (fr + 1) << 8;
             if (out_lane && sr >= r0 && sr < r1) {
+                const unsigned po = (unsigned)(sr * W + pxr);
                 at32(idx_s + (size_t)b * HW, po) = (uint8_t)bi;
                 if (to_opt_s) at32(to_opt_s + (size_t)b * HW, po) = best;
                 acc += (double)best;
             }
         } else {
-            selh[2] = -1;
 #pragma unroll
             for (int c = 0; c < 3; ++c)
 #pragma unroll
                 for (int k = 0; k < 3; ++k) ch[2][c][k] = 0.f;
         }
+        prefetch_ssim_row(sr + 1);   // behind its last use: one step of cover, no second copy of the values
 
+        MDX_STAMP(2);   // SSIM phase
         // ================= (3) gradient of row gr =================
         if (t < 4) continue;
         const float wy0 = gr == 1 ? 2.f : 1.f, wy2 = gr == H - 2 ? 2.f : 1.f;   // reflection-pad fold (y)
         float r3[3];
-        pixel_ray(invK_b, fpx, (float)gr, r3);
+        pixel_ray(iK, fpx, (float)gr, r3);
         const float depth = dph[0];
-        const float X[4] = {depth * r3[0], depth * r3[1], depth * r3[2], 1.0f};
+        const float fgr = (float)gr;
+        const int sel0 = selp & 15, sel1 = (selp >> 4) & 15, sel2 = (selp >> 8) & 15;
         float gdepth = 0.f;
 #pragma unroll
         for (int f = 0; f < S; ++f) {
-            const int own = (selh[0] == f) | (selh[1] == f) | (selh[2] == f);
+            const int own = (sel0 == f + 1) | (sel1 == f + 1) | (sel2 == f + 1);
             const int hit = own | dpp_i<0x138>(own) | dpp_i<0x130>(own);
             if (__builtin_amdgcn_ballot_w64(hit != 0 && out_lane) == 0) continue;   // wave-uniform
-            const float w0 = selh[0] == f ? wy0 : 0.f, w1 = selh[1] == f ? 1.f : 0.f, w2 = selh[2] == f ? wy2 : 0.f;
+            const float w0 = sel0 == f + 1 ? wy0 : 0.f, w1 = sel1 == f + 1 ? 1.f : 0.f, w2 = sel2 == f + 1 ? wy2 : 0.f;
             const float4 sa = s_stash[slot_r][2 * f][lane], sb = s_stash[slot_r][2 * f + 1][lane];
             const float du[3] = {sa.x, sa.y, sa.z}, dv[3] = {sb.x, sb.y, sb.z};
-            const bool centre = selh[1] == f;
+            const bool centre = sel1 == f + 1;
             float gu = 0.f, gv = 0.f;
+            // vertical 3-tap sums (own column, registers) of all nine coefficient maps first, then -- behind a
+            // scheduling barrier, see the note on DPP operands above -- the horizontal ones (neighbour lanes)
+            float vs[3][3], sum3[3][3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                float sum3[3];
+            for (int c = 0; c < 3; ++c)
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    // vertical (own column, registers) then horizontal (neighbour lanes) 3-tap sums
                     float v = w0 * ch[0][c][k];
                     v = __builtin_fmaf(w1, ch[1][c][k], v);
-                    v = __builtin_fmaf(w2, ch[2][c][k], v);
-                    float s = __builtin_fmaf(from_left(v), wx0, v);
-                    sum3[k] = __builtin_fmaf(from_right(v), wx2, s);
+                    vs[c][k] = __builtin_fmaf(w2, ch[2][c][k], v);
                 }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float s = __builtin_fmaf(from_left(vs[c][k]), wx0, vs[c][k]);
+                    sum3[c][k] = __builtin_fmaf(from_right(vs[c][k]), wx2, s);
+                }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
                 const float xq = xh[0][f][c], yq = yh[0][c];
-                float gx = (sum3[0] + 2.0f * xq * sum3[1] + yq * sum3[2]) * (1.0f / 9.0f);
+                float gx = (sum3[c][0] + 2.0f * xq * sum3[c][1] + yq * sum3[c][2]) * (1.0f / 9.0f);
                 if (centre) gx -= 0.05f * ((yq > xq) ? 1.f : ((yq < xq) ? -1.f : 0.f));   // 0.15*mean_c|y-x|
                 gu += gx * du[c];
                 gv += gx * dv[c];
             }
             // grid normalisation (2/(W-1)) and grid_sample's un-normalisation ((W-1)/2) cancel
-            gu = (((flh[0] >> (2 * f)) & 1) && out_lane) ? gu : 0.f;
-            gv = (((flh[0] >> (2 * f + 1)) & 1) && out_lane) ? gv : 0.f;
-            const float *Pf = P_s + ((size_t)f * d.B + b) * 12;
-            float z = Pf[8] * X[0];
-            z = __builtin_fmaf(Pf[9], X[1], z);
-            z = __builtin_fmaf(Pf[10], X[2], z);
+            gu = (((flp >> (2 * f)) & 1) && out_lane) ? gu : 0.f;
+            gv = (((flp >> (2 * f + 1)) & 1) && out_lane) ? gv : 0.f;
+            const float *Pf = Pm[f];
+            const float X0 = depth * r3[0], X1 = depth * r3[1], X2 = depth * r3[2];
+            float z = Pf[8] * X0;
+            z = __builtin_fmaf(Pf[9], X1, z);
+            z = __builtin_fmaf(Pf[10], X2, z);
             z = __builtin_fmaf(Pf[11], 1.0f, z) + 1e-7f;
             const float iz = __builtin_amdgcn_rcpf(z);
-            const float gq0 = gu * iz, gq1 = gv * iz, gq2 = -(gu * sa.w + gv * sb.w) * iz;
+            const float gq[3] = {gu * iz, gv * iz, -(gu * sa.w + gv * sb.w) * iz};
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                const float gX = gq0 * Pf[j] + gq1 * Pf[4 + j] + gq2 * Pf[8 + j];
+                const float gX = gq[0] * Pf[j] + gq[1] * Pf[4 + j] + gq[2] * Pf[8 + j];
                 gdepth += gX * r3[j];
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                accP[f][j] += gq0 * X[j];
-                accP[f][4 + j] += gq1 * X[j];
-                accP[f][8 + j] += gq2 * X[j];
+            for (int i = 0; i < 3; ++i) {
+                const float gd = gq[i] * depth;
+                accA[f][i] += gd;
+                accB[f][i] = __builtin_fmaf(fgr, gd, accB[f][i]);
+                accC[f][i] += gq[i];
             }
         }
         // depth = 1/(a + b*disp)  ->  d depth / d disp = -b * depth^2
         if (out_lane) at32(gup_s + (size_t)b * HW, (unsigned)(gr * W + pxr)) = gdepth * (-d.disp_b * depth * depth);
+        MDX_STAMP(3);   // gradient phase
     }
+#ifdef MDX_TRAIN_STAMPS
+    if (lane == 0 && a.stamps) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a.stamps[(size_t)item * 8 + k] = st_acc[k];
+        a.stamps[(size_t)item * 8 + 4] = __builtin_amdgcn_s_memtime() - st_begin;
+        a.stamps[(size_t)item * 8 + 5] = (unsigned long long)nsteps;
+        a.stamps[(size_t)item * 8 + 6] = st_begin;
+        a.stamps[(size_t)item * 8 + 7] = (unsigned long long)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);   // XCC_ID
+    }
+#endif
 
     // ---- per-item partials: d(P) (register reduction, total in lane 63) and the loss sum ----
+    // d(P)[i][j] = sum gq_i * depth * r_j,  r_j = k_j0*px + k_j1*py + k_j2  (j < 3);  d(P)[i][3] = sum gq_i
 #pragma unroll
     for (int f = 0; f < S; ++f)
 #pragma unroll
-        for (int k = 0; k < 12; ++k) {
-            const float tot = wave_sum_dpp_lane63(accP[f][k]);
-            if (lane == 63) a.partP[(size_t)item * (S * 12) + f * 12 + k] = tot;
+        for (int i = 0; i < 3; ++i) {
+            const float sA = wave_sum_dpp_lane63(accA[f][i]);
+            const float sAx = wave_sum_dpp_lane63(accA[f][i] * fpx);
+            const float sB = wave_sum_dpp_lane63(accB[f][i]);
+            const float sC = wave_sum_dpp_lane63(accC[f][i]);
+            if (lane == 63) {
+                float *o = a.partP + (size_t)item * (S * 12) + f * 12 + i * 4;
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    o[j] = iK[j * 4 + 0] * sAx + iK[j * 4 + 1] * sB + iK[j * 4 + 2] * sA;
+                o[3] = sC;
+            }
         }
     acc = wave_sum(acc);
     if (lane == 0) a.loss_part[item] = acc;
@@ -418,6 +603,9 @@ static TrainPlan plan(const mdx_train_desc *d)
     p.off_partP = p.items * sizeof(double);
     p.off_gup = p.off_partP + ((p.items * d->S * 12 * sizeof(float) + 15) & ~(size_t)15);
     p.total = p.off_gup + (size_t)d->nscales * d->B * d->H * d->W * sizeof(float);
+#ifdef MDX_TRAIN_STAMPS
+    p.total += p.items * 8 * sizeof(unsigned long long);
+#endif
     return p;
 }
 
@@ -499,6 +687,9 @@ MDX_EXPORT int mdx_photometric_train(const mdx_train_desc *d, const float *const
         a.h[s] = a.h[0]; a.w[s] = a.w[0]; a.disp[s] = a.disp[0]; a.P[s] = a.P[0]; a.noise[s] = a.noise[0];
         a.idx[s] = a.idx[0]; a.gup[s] = a.gup[0]; a.to_opt[s] = a.to_opt[0];
     }
+#ifdef MDX_TRAIN_STAMPS
+    a.stamps = (unsigned long long *)((char *)workspace + p.total - p.items * 8 * sizeof(unsigned long long));
+#endif
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)p.items), block(64);
     if (t && t->start) (void)hipEventRecord((hipEvent_t)t->start, st);

@@ -154,6 +154,22 @@ def main():
             v = C.c_float()
             _lib.check(lib.mdx_event_elapsed_us(C.c_void_p(hk.start), C.c_void_p(hk.stop), C.byref(v)), "elapsed")
             us.append(v.value)
+        if os.environ.get("MDX_TRAIN_STAMPS"):   # diagnostic library build: per-item phase clocks at the workspace's end
+            items = int(os.environ["MDX_TRAIN_STAMPS"])
+            torch.cuda.synchronize()
+            st = ws.view(torch.int64).reshape(-1)[-(items * 8 + 2):-2].reshape(items, 8).cpu().double()
+            # the tensor is a little larger than the workspace: find the block by its step-count column
+            raw = ws.view(torch.int64).reshape(-1).cpu()
+            nb = nws // 8
+            st = raw[nb - items * 8:nb].reshape(items, 8).double()
+            steps = st[:, 5]
+            print("stamps: items %d, steps/item %.1f; cycles per step: issue %.0f  sample %.0f  ssim %.0f  grad %.0f ; "
+                  "item lifetime %.0f cycles (%.1f us at 100 MHz ticks?)" % (
+                      items, steps.mean(), (st[:, 0] / steps).mean(), (st[:, 1] / steps).mean(),
+                      (st[:, 2] / steps).mean(), (st[:, 3] / steps).mean(), st[:, 4].mean(), st[:, 4].mean() / 100.0))
+            t0 = st[:, 6] - st[:, 6].min()
+            print("   start offsets (ticks): median %.0f max %.0f ; lifetime min %.0f max %.0f" % (
+                t0.median(), t0.max(), st[:, 4].min(), st[:, 4].max()))
         masked = [100.0 * float((i < S).float().mean()) for i in idxs]
         print("train (%d scales, rows/chunk %d): whole call %.1f us, fused kernel %.1f us (min %.1f)  masked %s"
               % (nsc, a.rows, 1e3 * e0.elapsed_time(e1) / a.reps, sum(us) / len(us), min(us),
