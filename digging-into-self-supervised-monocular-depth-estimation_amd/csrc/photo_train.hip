@@ -18,6 +18,9 @@
 //     terms (bilinear x taps of the disparity, the x part of the pixel ray, reflection) are computed once per item;
 //   * LDS is only a per-lane stash ring (3 rows) for the sampling derivatives a row's gradient needs two rows later.
 // Arithmetic and its order are those of photo_fwd.hip / mdx_device.hpp (bit-exact per-pixel values, same arg-min).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include "photo_common.hpp"
 
 namespace mdx {
@@ -29,7 +32,11 @@ struct TrainArgs {
     unsigned flags;
     float disp_a, disp_b;
     int h[MDX_MAX_SCALES], w[MDX_MAX_SCALES];
-    int rows, nchunks, nstrips;
+    // guided schedule: every column (scale, image, strip) is cut into lev_n[0] chunks of lev_r[0] rows, then lev_n[1] of
+    // lev_r[1], then lev_n[2] of lev_r[2] (the last one may be ragged); items are numbered level by level, so the
+    // large chunks are dispatched first and the small ones fill the tail of the launch
+    int lev_n[3], lev_r[3], lev_item0[3], lev_row0[3], lev_k0[3];
+    int nchunks, nstrips, ncols;
     const float *disp[MDX_MAX_SCALES];
     const float *P[MDX_MAX_SCALES];
     const float *noise[MDX_MAX_SCALES];
@@ -62,6 +69,11 @@ struct TrainArgs {
 // wave-uniform selection from a by-value kernel-argument array without dynamic indexing (which would send the
 // argument block to scratch)
 template <typename T> MDX_DEV T pick(const T (&v)[MDX_MAX_SCALES], int s)
+{
+    return s == 0 ? v[0] : (s == 1 ? v[1] : (s == 2 ? v[2] : v[3]));
+}
+
+MDX_DEV int pick4(const int (&v)[MDX_MAX_SCALES + 1], int s)
 {
     return s == 0 ? v[0] : (s == 1 ? v[1] : (s == 2 ? v[2] : v[3]));
 }
@@ -158,16 +170,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S <= 2 ? 3 :
     __shared__ float4 s_stash[3][2 * S][64];
 
     const int lane = threadIdx.x;
-    // ---- work item, XCD-aware (photo_common.hpp tile_id): the blocks of one XCD walk a contiguous run of items ----
-    const unsigned nwg = gridDim.x, orig = blockIdx.x;
-    const unsigned qq = nwg / 8, rr = nwg % 8, xcd = orig % 8;
-    const unsigned item = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + orig / 8;
-    const int strip = (int)(item % (unsigned)a.nstrips);
-    unsigned rest = item / (unsigned)a.nstrips;
-    const int chunk = (int)(rest % (unsigned)a.nchunks);
-    rest /= (unsigned)a.nchunks;
-    const int b = (int)(rest % (unsigned)a.B);
-    const int scale = (int)(rest / (unsigned)a.B);
+    // ---- work item: level-major order (see TrainArgs), dispatched in block order ----
+    const int item_d = (int)blockIdx.x;
+    const int lev = item_d >= a.lev_item0[2] ? 2 : (item_d >= a.lev_item0[1] ? 1 : 0);
+    const int lev_first = lev == 2 ? a.lev_item0[2] : (lev == 1 ? a.lev_item0[1] : a.lev_item0[0]);
+    const int lev_rows = lev == 2 ? a.lev_r[2] : (lev == 1 ? a.lev_r[1] : a.lev_r[0]);
+    const int kk = (item_d - lev_first) / a.ncols, colid = (item_d - lev_first) % a.ncols;
+    const int strip = colid % a.nstrips;
+    const int b = (colid / a.nstrips) % a.B;
+    const int scale = colid / (a.nstrips * a.B);
+    const int chunk = (lev == 2 ? a.lev_k0[2] : (lev == 1 ? a.lev_k0[1] : a.lev_k0[0])) + kk;
+    // slot of the item's partials: the items of one (scale, image) contiguous, whatever the dispatch order
+    const unsigned item = (unsigned)(((scale * a.B + b) * a.nchunks + chunk) * a.nstrips + strip);
 
     mdx_desc d;
     d.B = a.B; d.H = a.H; d.W = a.W; d.S = S; d.flags = a.flags; d.disp_a = a.disp_a; d.disp_b = a.disp_b;
@@ -199,7 +213,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S <= 2 ? 3 :
     const UpTap tx = up_tap((float)d.w / (float)W, pxr, d.w);
     const float fpx = (float)pxr;
 
-    const int r0 = chunk * a.rows, r1 = min(r0 + a.rows, H);
+    const int r0 = (lev == 2 ? a.lev_row0[2] : (lev == 1 ? a.lev_row0[1] : a.lev_row0[0])) + kk * lev_rows;
+    const int r1 = min(r0 + lev_rows, H);
 
     // ---- the item's matrices, once, as wave-uniform scalars (inside the loop they would be re-fetched through vector
     //      memory every row and consumed at once: two exposed cache round trips per row) ----
@@ -269,6 +284,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S <= 2 ? 3 :
     };
     prefetch_warp_row(r0 - 2);
     prefetch_ssim_row(r0 - 3);
+    // The gradient row of a step is stored in the NEXT step, behind that step's load issue: the memory counter wait
+    // at the top of a step (everything outstanding, the loop edge makes it conservative) would otherwise sit right
+    // behind a store that has only just been issued.
+    float gup_val = 0.f;
+    int gup_row = -1;
 
 #ifdef MDX_TRAIN_STAMPS
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -323,6 +343,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S <= 2 ? 3 :
                 for (int c = 0; c < 3; ++c)
                     cn[f][c] = load_corners(a.src.img[f] + ((size_t)b * 3 + c) * HW, H, W, tp[f]);
             prefetch_warp_row(wr + 1);
+            if (gup_row >= 0 && out_lane) at32(gup_s + (size_t)b * HW, (unsigned)(gup_row * W + pxr)) = gup_val;
+            gup_row = -1;
             MDX_STAMP(0);   // geometry, taps, load issue
             int fl = 0;
 #pragma unroll
@@ -521,15 +543,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S <= 2 ? 3 :
             }
         }
         // depth = 1/(a + b*disp)  ->  d depth / d disp = -b * depth^2
-        if (out_lane) at32(gup_s + (size_t)b * HW, (unsigned)(gr * W + pxr)) = gdepth * (-d.disp_b * depth * depth);
+        gup_val = gdepth * (-d.disp_b * depth * depth);
+        gup_row = gr;
         MDX_STAMP(3);   // gradient phase
     }
+    if (gup_row >= 0 && out_lane) at32(gup_s + (size_t)b * HW, (unsigned)(gup_row * W + pxr)) = gup_val;
 #ifdef MDX_TRAIN_STAMPS
     if (lane == 0 && a.stamps) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) a.stamps[(size_t)item * 8 + k] = st_acc[k];
         a.stamps[(size_t)item * 8 + 4] = __builtin_amdgcn_s_memtime() - st_begin;
-        a.stamps[(size_t)item * 8 + 5] = (unsigned long long)nsteps;
+        a.stamps[(size_t)item * 8 + 5] = (unsigned long long)nsteps |
+                                         ((unsigned long long)__builtin_amdgcn_s_getreg(((16 - 1) << 11) | (0 << 6) | 4) << 32);   // HW_ID[15:0]
         a.stamps[(size_t)item * 8 + 6] = st_begin;
         a.stamps[(size_t)item * 8 + 7] = (unsigned long long)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);   // XCC_ID
     }
@@ -557,49 +582,207 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S <= 2 ? 3 :
     if (lane == 0) a.loss_part[item] = acc;
 }
 
-// Second pass, fixed order (deterministic): one wave64 per output.
-//   blocks [0, nscales*S*B*12): gP[scale][f][b][k] = sum over the items of (scale, b)
-//   blocks [nscales*S*B*12, +nscales): loss_sum[scale]
-__global__ __launch_bounds__(64) void train_finish_kernel(const float *__restrict__ partP,
-                                                          const double *__restrict__ loss_part, int nscales, int S,
-                                                          int B, int ipi, float *__restrict__ gP,
-                                                          float *__restrict__ loss_sum)
+// ---------------------------------------------------------------------------------------------
+// Second pass, ONE launch, fixed summation orders (deterministic):
+//   * transpose of the bilinear upsample (autograd of warp.py:18-20) of every scale below full resolution:
+//     LPO lanes share one low-resolution pixel, each takes every LPO-th row of its footprint (x weights of the
+//     footprint in registers), a shuffle tree adds them;
+//   * d(P)[scale][f][b][k] = sum over the items of (scale, b) -- one wave64 per output;
+//   * loss_sum[scale].
+// ---------------------------------------------------------------------------------------------
+struct FinishArgs {
+    const float *gup[MDX_MAX_SCALES];
+    float *gin[MDX_MAX_SCALES];
+    int h[MDX_MAX_SCALES], w[MDX_MAX_SCALES];
+    int up_first[MDX_MAX_SCALES + 1];   // first block of each scale's upsample job (equal = no job)
+    int B, H, W, nscales, S, ipi;
+    const float *partP;
+    const double *loss_part;
+    float *gP, *loss_sum;
+};
+
+// first / last output index whose bilinear source index scale*(dst+0.5)-0.5 can fall in (i-1, i+1), with a margin of
+// one (the weights decide; the margin only has to cover the rounding of this estimate)
+MDX_DEV int foot_lo(int i, float inv_scale) { return (int)floorf(((float)i - 0.5f) * inv_scale - 0.5f) - 1; }
+MDX_DEV int foot_hi(int i, float inv_scale) { return (int)ceilf(((float)i + 1.5f) * inv_scale - 0.5f) + 1; }
+
+template <int NW, int LPO>
+MDX_DEV void upsample_bwd_body(const float *__restrict__ gout, int BC, int H, int W, float *__restrict__ gin, int h,
+                               int w, unsigned block, float *s_wx)
 {
-    const int i = blockIdx.x, ngp = nscales * S * B * 12;
-    double acc = 0.0;
-    if (i < ngp) {
-        const int k = i % 12, bb = (i / 12) % B, f = (i / (12 * B)) % S, sc = i / (12 * B * S);
-        const float *p = partP + ((size_t)(sc * B + bb) * ipi) * (S * 12) + f * 12 + k;
-        for (int t = threadIdx.x; t < ipi; t += 64) acc += (double)p[(size_t)t * (S * 12)];
+    constexpr int NOUT = NT / LPO;            // low-resolution pixels per block
+    const size_t n = (size_t)BC * h * w;
+    const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+    const float isy = (float)H / (float)h, isx = (float)W / (float)w;
+    // x weights of the block's pixels, computed once per block (every lane of a pixel, and every row, shares them)
+    for (int e = threadIdx.x; e < NOUT * NW; e += NT) {
+        const int oo = e / NW, t = e - oo * NW;
+        const size_t o2 = min((size_t)block * NOUT + oo, n - 1);
+        const int jx2 = (int)(o2 % w);
+        const int xa2 = max(0, foot_lo(jx2, isx)), xb2 = min(W - 1, foot_hi(jx2, isx));
+        const int x = xa2 + t;
+        const UpTap tx = up_tap(sx, x <= xb2 ? x : xb2, w);
+        s_wx[e] = x <= xb2 ? (tx.i0 == jx2 ? tx.l0 : 0.f) + (tx.i1 == jx2 ? tx.l1 : 0.f) : 0.f;
+    }
+    __syncthreads();
+    const int oo = threadIdx.x / LPO, l = threadIdx.x % LPO;
+    const size_t oraw = (size_t)block * NOUT + oo;
+    const size_t o = min(oraw, n - 1);
+    const int jx = (int)(o % w), iy = (int)((o / w) % h);
+    const size_t bc = o / ((size_t)w * h);
+    const int ya = max(0, foot_lo(iy, isy)), yb = min(H - 1, foot_hi(iy, isy));
+    const int xa = max(0, foot_lo(jx, isx));
+    const float *g = gout + bc * (size_t)H * W;
+    // a lane's rows: ya + l, ya + l + LPO, ...; the footprint has at most NW rows, so NIT rounds cover it.  All loads
+    // of all rounds are issued before the first is consumed (one memory round trip per pixel instead of one per row).
+    constexpr int NIT = (NW + LPO - 1) / LPO;
+    float v[NIT][NW], wy[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int y = ya + l + it * LPO;
+        const int yc = min(y, yb);
+        const UpTap ty = up_tap(sy, yc, h);
+        wy[it] = y <= yb ? (ty.i0 == iy ? ty.l0 : 0.f) + (ty.i1 == iy ? ty.l1 : 0.f) : 0.f;
+        const float *row = g + (size_t)yc * W;
+#pragma unroll
+        for (int t = 0; t < NW; ++t) v[it][t] = row[min(xa + t, W - 1)];
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        float rs = 0.f;
+#pragma unroll
+        for (int t = 0; t < NW; ++t) rs = __builtin_fmaf(s_wx[oo * NW + t], v[it][t], rs);
+        acc = __builtin_fmaf(wy[it], rs, acc);
+    }
+#pragma unroll
+    for (int m = 1; m < LPO; m <<= 1) acc += __shfl_xor(acc, m, 64);
+    if (l == 0 && oraw < n) gin[o] = acc;
+}
+
+// lanes per low-resolution pixel and footprint width by ratio (2*ratio + 3 columns); wider: the per-scale kernels
+static int finish_lpo(int W, int w)
+{
+    const int foot = (int)ceilf(2.0f * (float)W / (float)w) + 3;
+    return foot <= 8 ? 4 : (foot <= 12 ? 8 : (foot <= 20 ? 16 : 0));
+}
+
+__global__ __launch_bounds__(NT) void train_finish_kernel(FinishArgs a)
+{
+    __shared__ float s_wx[512];   // NOUT * NW: 64*8, 32*12, 16*20
+    const int blk = blockIdx.x;
+    if (blk < a.up_first[MDX_MAX_SCALES]) {
+        const int sc = blk >= a.up_first[3] ? 3 : (blk >= a.up_first[2] ? 2 : (blk >= a.up_first[1] ? 1 : 0));
+        const float *gup = pick(a.gup, sc);
+        float *gin = pick(a.gin, sc);
+        const int h = pick(a.h, sc), w = pick(a.w, sc);
+        const unsigned rel = (unsigned)(blk - pick4(a.up_first, sc));
+        const int foot = (int)ceilf(2.0f * (float)a.W / (float)w) + 3;
+        if (foot <= 8) upsample_bwd_body<8, 4>(gup, a.B, a.H, a.W, gin, h, w, rel, s_wx);
+        else if (foot <= 12) upsample_bwd_body<12, 8>(gup, a.B, a.H, a.W, gin, h, w, rel, s_wx);
+        else upsample_bwd_body<20, 16>(gup, a.B, a.H, a.W, gin, h, w, rel, s_wx);
+        return;
+    }
+    // reductions.  Loads are issued in groups of four independent ones (a dependent load -> add chain would pay one
+    // memory round trip per element); the order of the additions is fixed.
+    __shared__ double s_red[NT / 64];
+    const int rblk = blk - a.up_first[MDX_MAX_SCALES];
+    const int lane = threadIdx.x & 63;
+    const int ngp = a.nscales * a.S * a.B * 12;
+    const int ngp_blocks = (ngp + NT / 64 - 1) / (NT / 64);
+    if (rblk < ngp_blocks) {            // d(P): one wave64 per output, four outputs per block
+        const int i = rblk * (NT / 64) + (threadIdx.x >> 6);
+        if (i >= ngp) return;
+        const int k = i % 12, bb = (i / 12) % a.B, f = (i / (12 * a.B)) % a.S, sc = i / (12 * a.B * a.S);
+        const float *p = a.partP + ((size_t)(sc * a.B + bb) * a.ipi) * (a.S * 12) + f * 12 + k;
+        const size_t stride = (size_t)a.S * 12;
+        double acc = 0.0;
+        for (int t = lane; t < a.ipi; t += 256) {
+            const float v0 = p[(size_t)t * stride];
+            const float v1 = t + 64 < a.ipi ? p[(size_t)(t + 64) * stride] : 0.f;
+            const float v2 = t + 128 < a.ipi ? p[(size_t)(t + 128) * stride] : 0.f;
+            const float v3 = t + 192 < a.ipi ? p[(size_t)(t + 192) * stride] : 0.f;
+            acc += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+        }
         acc = wave_sum(acc);
-        if (threadIdx.x == 0) gP[i] = (float)acc;
-    } else {
-        const int sc = i - ngp;
-        const double *p = loss_part + (size_t)sc * B * ipi;
-        for (int t = threadIdx.x; t < B * ipi; t += 64) acc += p[t];
+        if (lane == 0) a.gP[i] = (float)acc;
+    } else {                            // loss_sum[scale]: one block per scale
+        const int sc = rblk - ngp_blocks;
+        if (sc >= a.nscales) return;
+        const double *p = a.loss_part + (size_t)sc * a.B * a.ipi;
+        const int cnt = a.B * a.ipi;
+        double acc = 0.0;
+        for (int t = threadIdx.x; t < cnt; t += 4 * NT) {
+            const double v0 = p[t];
+            const double v1 = t + NT < cnt ? p[t + NT] : 0.0;
+            const double v2 = t + 2 * NT < cnt ? p[t + 2 * NT] : 0.0;
+            const double v3 = t + 3 * NT < cnt ? p[t + 3 * NT] : 0.0;
+            acc += (v0 + v1) + (v2 + v3);
+        }
         acc = wave_sum(acc);
-        if (threadIdx.x == 0) loss_sum[sc] = (float)acc;
+        if (lane == 0) s_red[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) a.loss_sum[sc] = (float)((s_red[0] + s_red[1]) + (s_red[2] + s_red[3]));
     }
 }
 
-static int default_rows(const mdx_train_desc *d)
-{
-    // enough items to fill the 256 CUs a few waves deep, few enough that the 4 halo rows of a chunk stay cheap
-    const int nstrips = (d->W + SW - 1) / SW;
-    int rows = 32;
-    while (rows > 8 && (long long)d->nscales * d->B * ((d->H + rows - 1) / rows) * nstrips < 6144) rows /= 2;
-    return rows;
-}
+struct TrainPlan {
+    int lev_n[3], lev_r[3], lev_item0[3], lev_row0[3], lev_k0[3];
+    int nchunks, nstrips, ncols;
+    size_t items, off_partP, off_gup, total;
+};
 
-struct TrainPlan { int rows, nchunks, nstrips; size_t items, off_partP, off_gup, total; };
+// Chunk schedule of a column of H rows.  rows_per_chunk > 0: uniform chunks of that many rows (tests, sweeps).
+// 0: guided -- about 60 % of the rows in large chunks (4 halo rows per chunk cost little), 25 % in chunks half as
+// tall, the rest in small ones that end the launch without a long ragged tail (a work item is one wave walking
+// rows + 4 steps; their cost also varies with the auto-mask pattern).  MDX_TRAIN_SCHEDULE="r1,f1,r2,f2,r3" overrides
+// (rows of the levels, fractions of H in levels 1 and 2) for tuning.
+static void choose_levels(const mdx_train_desc *d, TrainPlan &p)
+{
+    const int H = d->H;
+    int r[3] = {0, 0, 0};
+    double f1 = 0.6, f2 = 0.25;
+    if (d->rows_per_chunk > 0) {
+        r[0] = r[1] = r[2] = d->rows_per_chunk;
+        f1 = f2 = 0.0;
+    } else {
+        r[0] = H >= 160 ? 40 : (H >= 64 ? 24 : 16);
+        r[1] = r[0] / 2;
+        r[2] = r[1] / 2 > 4 ? r[1] / 2 : 4;
+        if (const char *e = getenv("MDX_TRAIN_SCHEDULE")) {
+            int a0, a1, a2;
+            double g1, g2;
+            if (sscanf(e, "%d,%lf,%d,%lf,%d", &a0, &g1, &a1, &g2, &a2) == 5 && a0 > 0 && a1 > 0 && a2 > 0 && g1 >= 0 &&
+                g2 >= 0 && g1 + g2 <= 1.0) {
+                r[0] = a0; r[1] = a1; r[2] = a2; f1 = g1; f2 = g2;
+            }
+        }
+    }
+    int row = 0, k = 0;
+    for (int l = 0; l < 3; ++l) {
+        int n;
+        if (l == 2) {
+            n = (H - row + r[l] - 1) / r[l];                 // the rest, last chunk ragged
+        } else {
+            n = (int)((l == 0 ? f1 : f2) * H / r[l]);
+            if (row + n * r[l] > H) n = (H - row) / r[l];
+        }
+        p.lev_n[l] = n; p.lev_r[l] = r[l]; p.lev_row0[l] = row; p.lev_k0[l] = k;
+        row += n * r[l];
+        k += n;
+    }
+    p.nchunks = k;
+}
 
 static TrainPlan plan(const mdx_train_desc *d)
 {
     TrainPlan p;
-    p.rows = d->rows_per_chunk > 0 ? d->rows_per_chunk : default_rows(d);
-    p.nchunks = (d->H + p.rows - 1) / p.rows;
+    choose_levels(d, p);
     p.nstrips = (d->W + SW - 1) / SW;
-    p.items = (size_t)d->nscales * d->B * p.nchunks * p.nstrips;
+    p.ncols = d->nscales * d->B * p.nstrips;
+    int it = 0;
+    for (int l = 0; l < 3; ++l) { p.lev_item0[l] = it; it += p.lev_n[l] * p.ncols; }
+    p.items = (size_t)p.ncols * p.nchunks;
     p.off_partP = p.items * sizeof(double);
     p.off_gup = p.off_partP + ((p.items * d->S * 12 * sizeof(float) + 15) & ~(size_t)15);
     p.total = p.off_gup + (size_t)d->nscales * d->B * d->H * d->W * sizeof(float);
@@ -669,7 +852,11 @@ MDX_EXPORT int mdx_photometric_train(const mdx_train_desc *d, const float *const
     TrainArgs a = {};
     a.B = d->B; a.H = d->H; a.W = d->W; a.S = d->S; a.nscales = d->nscales; a.flags = d->flags;
     a.disp_a = d->disp_a; a.disp_b = d->disp_b;
-    a.rows = p.rows; a.nchunks = p.nchunks; a.nstrips = p.nstrips;
+    for (int l = 0; l < 3; ++l) {
+        a.lev_n[l] = p.lev_n[l]; a.lev_r[l] = p.lev_r[l]; a.lev_item0[l] = p.lev_item0[l];
+        a.lev_row0[l] = p.lev_row0[l]; a.lev_k0[l] = p.lev_k0[l];
+    }
+    a.nchunks = p.nchunks; a.nstrips = p.nstrips; a.ncols = p.ncols;
     a.target = target; a.ident = ident; a.invK = invK; a.src = *src; a.depth0 = depth0;
     a.loss_part = (double *)workspace;
     a.partP = (float *)((char *)workspace + p.off_partP);
@@ -702,13 +889,29 @@ MDX_EXPORT int mdx_photometric_train(const mdx_train_desc *d, const float *const
     }
     if (t && t->stop) (void)hipEventRecord((hipEvent_t)t->stop, st);
     if ((rc = check_launch())) return rc;
-    const int ngp = d->nscales * d->S * d->B * 12;
-    hipLaunchKernelGGL(train_finish_kernel, dim3(ngp + d->nscales), dim3(64), 0, st, a.partP, a.loss_part, d->nscales,
-                       d->S, d->B, p.nchunks * p.nstrips, gP, loss_sum);
-    if ((rc = check_launch())) return rc;
-    for (int s = 0; s < d->nscales; ++s) {
-        const bool same = d->h[s] == d->H && d->w[s] == d->W;
-        if (!same && (rc = launch_upsample_bwd(a.gup[s], d->B, d->H, d->W, gdisp[s], d->h[s], d->w[s], st))) return rc;
+    FinishArgs fa = {};
+    fa.B = d->B; fa.H = d->H; fa.W = d->W; fa.nscales = d->nscales; fa.S = d->S; fa.ipi = p.nchunks * p.nstrips;
+    fa.partP = a.partP; fa.loss_part = a.loss_part; fa.gP = gP; fa.loss_sum = loss_sum;
+    int nblk = 0;
+    bool separate[MDX_MAX_SCALES] = {false, false, false, false};
+    for (int s = 0; s < MDX_MAX_SCALES; ++s) {
+        fa.up_first[s] = nblk;
+        fa.gup[s] = a.gup[s < d->nscales ? s : 0]; fa.gin[s] = gdisp[s < d->nscales ? s : 0];
+        fa.h[s] = d->h[s < d->nscales ? s : 0]; fa.w[s] = d->w[s < d->nscales ? s : 0];
+        if (s >= d->nscales || (d->h[s] == d->H && d->w[s] == d->W)) continue;
+#ifdef MDX_TRAIN_STAMPS
+        if (const char *e = getenv("MDX_FINISH_SKIP")) if (strchr(e, '0' + s)) continue;   // diagnostic: leave a scale out
+#endif
+        const int lpo = finish_lpo(d->W, d->w[s]);
+        // the merged pass assumes one ratio for both axes and a footprint of at most 20 columns
+        if (lpo == 0 || (long long)d->H * d->w[s] != (long long)d->W * d->h[s]) { separate[s] = true; continue; }
+        nblk += (int)(((size_t)d->B * d->h[s] * d->w[s] * lpo + NT - 1) / NT);
     }
+    fa.up_first[MDX_MAX_SCALES] = nblk;
+    const int ngp_blocks = (d->nscales * d->S * d->B * 12 + NT / 64 - 1) / (NT / 64);
+    hipLaunchKernelGGL(train_finish_kernel, dim3(nblk + ngp_blocks + d->nscales), dim3(NT), 0, st, fa);
+    if ((rc = check_launch())) return rc;
+    for (int s = 0; s < d->nscales; ++s)
+        if (separate[s] && (rc = launch_upsample_bwd(a.gup[s], d->B, d->H, d->W, gdisp[s], d->h[s], d->w[s], st))) return rc;
     return MDX_OK;
 }

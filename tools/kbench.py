@@ -162,11 +162,30 @@ def main():
             raw = ws.view(torch.int64).reshape(-1).cpu()
             nb = nws // 8
             st = raw[nb - items * 8:nb].reshape(items, 8).double()
-            steps = st[:, 5]
+            hw = (raw[nb - items * 8:nb].reshape(items, 8)[:, 5] >> 32)
+            steps = (raw[nb - items * 8:nb].reshape(items, 8)[:, 5] & 0xffffffff).double()
+            xcc = raw[nb - items * 8:nb].reshape(items, 8)[:, 7] & 0xf
+            # gfx9 HW_ID: wave_id[3:0] simd_id[5:4] pipe_id[7:6] cu_id[11:8] sh_id[12] se_id[14:13]
+            simd_key = (xcc << 16) | (hw & 0x7f30)
+            import collections
+            per = collections.Counter(simd_key.tolist())
+            busy = collections.defaultdict(float)
+            for k, life in zip(simd_key.tolist(), st[:, 4].tolist()):
+                busy[k] += life
+            cnt = sorted(per.values())
+            bz = sorted(busy.values())
+            print("   placement: %d distinct SIMDs used; items per SIMD min %d median %d max %d; sum of item lifetimes per SIMD "
+                  "(cycles) min %.0f median %.0f max %.0f" % (len(per), cnt[0], cnt[len(cnt) // 2], cnt[-1], bz[0],
+                                                              bz[len(bz) // 2], bz[-1]))
+            end = st[:, 6] + st[:, 4]
+            print("   kernel span by stamps: %.0f ticks of the 100 MHz clock? first start -> last end" % (end.max() - st[:, 6].min()))
             print("stamps: items %d, steps/item %.1f; cycles per step: issue %.0f  sample %.0f  ssim %.0f  grad %.0f ; "
                   "item lifetime %.0f cycles (%.1f us at 100 MHz ticks?)" % (
                       items, steps.mean(), (st[:, 0] / steps).mean(), (st[:, 1] / steps).mean(),
                       (st[:, 2] / steps).mean(), (st[:, 3] / steps).mean(), st[:, 4].mean(), st[:, 4].mean() / 100.0))
+            if os.environ.get("MDX_STAMPS_DUMP"):
+                import numpy as np
+                np.save(os.environ["MDX_STAMPS_DUMP"], raw[nb - items * 8:nb].reshape(items, 8).numpy())
             t0 = st[:, 6] - st[:, 6].min()
             print("   start offsets (ticks): median %.0f max %.0f ; lifetime min %.0f max %.0f" % (
                 t0.median(), t0.max(), st[:, 4].min(), st[:, 4].max()))
