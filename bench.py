@@ -11,10 +11,12 @@ GPU, synthetic KITTI-shaped inputs resident in HBM.  Data parallel: one process 
 per-GPU work is fixed (weak scaling).  Prints ONE JSON line on rank 0.
 
 Extra objects in the line:
-  roofline      the dominant hand-written kernel (photometric forward or backward, whichever takes longer),
-                algorithmic bytes per launch (SURVEY 8d formula) / launch duration / 8 TB/s; the duration is the mean
-                over every launch of the timed steps, from HIP events the library records on the launch stream
-                right before and after the kernel (mdx_photometric_*_timed)
+  roofline      the dominant hand-written kernel: mdx::photometric_train_kernel (all scales, forward + gradient, one
+                launch per step).  achieved = algorithmic bytes per launch (per scale, forward + backward
+                formula, summed over the scales one launch processes) / launch duration; the duration is the mean over
+                every launch of the timed steps, from HIP events the library records on the launch stream right before
+                and after the kernel (mdx_photometric_train's timing hook).  The kernel is VALU-issue bound, not
+                HBM bound: the issue-side numbers of the committed PMC pass stand next to the HBM fraction.
   cpu_baseline  the same step on the host cores: torch-CPU networks + the CPU oracle for the loss path
                 (kind "port"), on a bounded sample (batch 4, configs[0])
 """
@@ -46,6 +48,7 @@ def make_opt(batch, height=192, width=640, frame_ids=(0, -1, 1), num_layers=18, 
     o.learning_rate, o.scheduler_step, o.epoch, o.save = 1e-4, 15, 1, "bench"
     o.num_workers, o.synthetic_length = workers, 2 * batch
     o.fused, o.noise, o.amp, o.channels_last = True, "device", amp, False
+    o.fused_train = True
     return o
 
 
@@ -157,6 +160,9 @@ def main():
     ap.add_argument("--no-miopen-db", action="store_true", help="ignore the shipped gfx950 find-db (MIOpen heuristics)")
     ap.add_argument("--graph", action="store_true",
                     help="capture the whole step (nets + fused loss + Adam) into ONE hipGraph and replay it (1 GPU)")
+    ap.add_argument("--per-scale-kernels", action="store_true",
+                    help="round-1 path: one fused forward + one backward kernel per scale instead of the one-launch "
+                         "training kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -184,6 +190,7 @@ def main():
     opt = make_opt(args.batch, height=args.height, width=args.width, frame_ids=frame_ids, num_layers=args.num_layers,
                    amp=args.amp)
     opt.channels_last = args.channels_last
+    opt.fused_train = not args.per_scale_kernels
     # MIOpen picks the tuned solvers from the shipped find-db in immediate mode already (fp32: same images/s as find
     # mode).  Find mode proper (--miopen-find) returns at once on a db hit but searches for minutes on a miss, so it
     # is never on by default; bf16 networks gain from it (a few more solvers are only reachable through find).
@@ -238,7 +245,7 @@ def main():
     # HIP events around every fused photometric kernel of the timed steps (recorded by the library on the launch
     # stream, right before / after the kernel): the roofline numbers below come from the very launches that are timed
     from mdx import functional as F
-    timing = {"fwd": [], "bwd": []} if (rank == 0 and not args.no_roofline and graph is None) else None
+    timing = {"fwd": [], "bwd": [], "train": []} if (rank == 0 and not args.no_roofline and graph is None) else None
     fence()
     F.TIMING = timing
     t0 = time.perf_counter()
@@ -249,7 +256,7 @@ def main():
     F.TIMING = None
     if rank == 0 and not args.no_roofline and graph is not None:
         # graph replay launches no Python: time the kernels over a few eager steps after the timed region instead
-        timing = {"fwd": [], "bwd": []}
+        timing = {"fwd": [], "bwd": [], "train": []}
         F.TIMING = timing
         for _ in range(5):
             step()
@@ -263,7 +270,7 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "images/sec training, KITTI 192x640 batch 12/GPU", "value": world * args.batch * args.steps / dt,
+            "metric": "images/sec training, KITTI %dx%d batch %d/GPU" % (args.height, args.width, args.batch), "value": world * args.batch * args.steps / dt,
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.amp == "none" else "bf16-nets/f32-loss", "data": "synthetic",
@@ -278,32 +285,53 @@ def main():
         }
         if not args.no_roofline and timing is not None:
             tsum = F.timing_summary(timing)
-            k = {n: {"ms": 1e-3 * tsum[n][0], "launches": tsum[n][1],
-                     "bytes": sum(alg_bytes(args.batch, opt.height, opt.width, len(frame_ids) - 1, sc, bwd=(n == "bwd"))
-                                  for sc in range(4)) / 4.0} for n in ("fwd", "bwd")}
-            dom = max(k, key=lambda n: k[n]["ms"])
+            nS = len(frame_ids) - 1
+            nsc = len(opt.scales)
+            per_scale = {n: sum(alg_bytes(args.batch, opt.height, opt.width, nS, sc, bwd=(n == "bwd"))
+                                for sc in range(nsc)) for n in ("fwd", "bwd")}
+            k = {}
+            if tsum.get("train", (0, 0))[1]:
+                k["train"] = {"ms": 1e-3 * tsum["train"][0], "launches": tsum["train"][1],
+                              "bytes": float(per_scale["fwd"] + per_scale["bwd"]),
+                              "name": "mdx::photometric_train_kernel<%d>" % nS}
+            for n, kn in (("fwd", "mdx::photometric_fwd_coef_kernel<%d>"), ("bwd", "mdx::photometric_bwd_coef_kernel<%d>")):
+                if tsum.get(n, (0, 0))[1]:
+                    k[n] = {"ms": 1e-3 * tsum[n][0], "launches": tsum[n][1], "bytes": per_scale[n] / float(nsc),
+                            "name": kn % nS}
             for n in k:
                 k[n]["GBs"] = k[n]["bytes"] / (k[n]["ms"] * 1e-3) / 1e9
-            nS = len(frame_ids) - 1
-            kname = {"fwd": "mdx::photometric_fwd_coef_kernel<%d>" % nS, "bwd": "mdx::photometric_bwd_coef_kernel<%d>" % nS}
-            # HBM-side bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE are
-            # collected in separate runs of tools/kbench.py; see profiles/r01_kernel_pmc.txt), null if absent
-            traffic = {}
+            dom = max(k, key=lambda n: k[n]["ms"] * k[n]["launches"])
+            # Counters of the committed rocprofv3 --pmc passes (tools/pmc_train.sh on tools/kbench.py's data, same
+            # shape).  They describe one build of the library: tied to it by the hash of libmdx_hip.so and to the
+            # workload by its shape; anything else reports null rather than a stale number.
+            traffic = issue = None
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_kernel_pmc.json")))
-                traffic = {n: pmc[kname[n]]["traffic_bytes"] for n in kname if kname[n] in pmc}
+                import hashlib
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_train_kernel_pmc.json")))
+                from mdx import LIB_PATH
+                so = hashlib.sha256(open(LIB_PATH, "rb").read()).hexdigest()[:16]
+                ent = pmc["kernels"].get(k[dom]["name"])
+                same_shape = pmc.get("shape") == [args.batch, opt.height, opt.width, nS, nsc]
+                if ent and same_shape and pmc.get("lib_sha16") == so:
+                    traffic = ent.get("traffic_bytes")
+                    issue = {kk: ent[kk] for kk in ("valu_wave_insts", "valu_issue_us", "wait_any_frac",
+                                                    "wait_inst_frac", "active_frac") if kk in ent}
             except (OSError, ValueError, KeyError):
                 pass
-            line["roofline"] = {"kernel": kname[dom], "bound": "hbm",
+            bound = "valu-issue" if (issue and issue.get("valu_issue_us", 0) > 0.3 * 1e3 * k[dom]["ms"]) else "hbm"
+            line["roofline"] = {"kernel": k[dom]["name"], "bound": bound if issue else "hbm (issue counters not available for this build)",
                                 "achieved": k[dom]["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": k[dom]["GBs"] / HBM_PEAK_GBS, "traffic": traffic.get(dom),
+                                "frac": k[dom]["GBs"] / HBM_PEAK_GBS, "traffic": traffic, "issue": issue,
                                 "launch_us": 1e3 * k[dom]["ms"], "alg_bytes_per_launch": k[dom]["bytes"],
                                 "launches_timed": k[dom]["launches"],
+                                "alg_bytes": "SURVEY 8d per scale (fwd: B*H*W*(12+12S+1)+B*h*w*4, bwd: ...+B*h*w*8), summed "
+                                             "over the %d scale(s) x {fwd,bwd} one launch covers" % (nsc if dom == "train" else 1),
                                 "timing": "HIP events recorded by the library around this kernel in the timed steps"}
-            other = "fwd" if dom == "bwd" else "bwd"
-            line["roofline_other"] = {"kernel": kname[other], "achieved": k[other]["GBs"],
-                                      "frac": k[other]["GBs"] / HBM_PEAK_GBS, "launch_us": 1e3 * k[other]["ms"],
-                                      "alg_bytes_per_launch": k[other]["bytes"]}
+            others = [n for n in k if n != dom]
+            if others:
+                line["roofline_other"] = [{"kernel": k[n]["name"], "achieved": k[n]["GBs"], "frac": k[n]["GBs"] / HBM_PEAK_GBS,
+                                           "launch_us": 1e3 * k[n]["ms"], "alg_bytes_per_launch": k[n]["bytes"]}
+                                          for n in others]
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))

@@ -3,11 +3,13 @@
     forward_depth   processor.py:33-55      forward_pose   processor.py:58-136
     image2warping   processor.py:139-163    compute_loss   processor.py:166-218
 
-With opt.fused (default) image2warping only forms the projection matrices and compute_loss runs ONE
-fused gfx950 kernel per scale (warp + SSIM/L1 + identity/noise + min); the identity losses, which do
-not depend on the scale, are evaluated once per step.  With opt.fused = False the reference's
-op-by-op sequence runs on the fine-grained kernels and every reference output key is populated
-(("warp_color", f, s), ...).  Results are identical between the two modes.
+With opt.fused (default) image2warping only forms the projection matrices.  compute_loss then runs, when gradients
+are wanted (training), ONE gfx950 kernel for all scales that evaluates the photometric term AND its gradient
+(opt.fused_train, default: mdx.functional.photometric_train, csrc/photo_train.hip); without gradients
+(validation) or with opt.fused_train = False one fused forward kernel per scale (+ one backward kernel per scale).
+The identity losses, which do not depend on the scale, are evaluated once per step.  With opt.fused = False the
+reference's op-by-op sequence runs on the fine-grained kernels and every reference output key is populated
+(("warp_color", f, s), ...).  Results are identical between the modes.
 """
 import torch
 
@@ -26,6 +28,7 @@ class compute(object):
         self.device = device
         self.num_pose_frames = len(opt.frame_ids) if opt.pose_frames == "all" else 2
         self.fused = _opt(opt, "fused", True)
+        self.fused_train = _opt(opt, "fused_train", True)
         # "device": N(0,1) drawn on the GPU; "cpu": the reference's torch.randn on the host + H2D copy
         # (processor.py:195) -- same stream of numbers as the reference for a given torch seed.
         self.noise_mode = _opt(opt, "noise", "device")
@@ -179,10 +182,31 @@ class compute(object):
         ident = None
         if self.fused and automask:
             ident = F.identity_loss(target, sources)          # once per step (scale-independent)
-        for scale in opt.scales:
+        # training: every scale's photometric term and its gradient in one launch.  The projection must not depend on
+        # the scale (posecnn scales the translation by the scale's depth: per-scale path).
+        train = None
+        if (self.fused and self.fused_train and torch.is_grad_enabled() and opt.pose_type != "posecnn"
+                and len(opt.scales) <= 4 and any(outputs[("disp", s)].requires_grad for s in opt.scales)):
+            nsc = len(opt.scales)
+            noises = None
+            if automask:
+                if all(("noise", s) in inputs for s in opt.scales):     # injected (parity tests)
+                    noises = [inputs[("noise", s)] for s in opt.scales]
+                else:
+                    noises = list(self._noise((nsc, B, S, H, W)).unbind(0))
+            train = F.photometric_train([outputs[("disp", s)].float() for s in opt.scales],
+                                        outputs[("P", opt.scales[0])], target, sources, inputs[("inv_K", 0)], ident,
+                                        noises, automask=automask, min_depth=opt.min_depth, max_depth=opt.max_depth,
+                                        need_depth=(opt.scales[0] == 0))
+            if train["depth"] is not None:
+                outputs[("depth", 0, 0)] = train["depth"]
+        for k, scale in enumerate(opt.scales):
             disp = outputs[("disp", scale)].float()
             color = inputs[("color", 0, scale)]
-            if self.fused:
+            if train is not None:
+                mean_min = train["sums"][k] / float(B * H * W)
+                outputs[("automask", scale)] = train["idx"][k]
+            elif self.fused:
                 noise = self._noise((B, S, H, W)) if automask else None
                 if ("noise", scale) in inputs:                 # injected (parity tests)
                     noise = inputs[("noise", scale)]

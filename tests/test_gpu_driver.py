@@ -1,5 +1,6 @@
 """GPU: the step driver `compute` (image2warping + compute_loss, reference processor.py:139-218) end to end
-against the reference's golden loss and gradients -- in fused mode (one kernel per scale) and in the op-by-op
+against the reference's golden loss and gradients -- with the one-launch training kernel (all scales, forward +
+gradient), in per-scale fused mode (one forward + one backward kernel per scale) and in the op-by-op
 mode that runs the reference's sequence on the fine-grained kernels (what a maintainer gets by swapping only
 model_layer / model_loss under the reference's own processor.py)."""
 import types
@@ -19,13 +20,14 @@ def G():
     return gpu_util
 
 
-def _setup(G, c, fused):
+def _setup(G, c, fused, fused_train=True):
     from model_tool.processor import compute
     from model_layer import Depth2PointCloud, PointCloud2Pixel
     from model_loss import ReprojectionLoss, SmoothLoss
     opt = types.SimpleNamespace(scales=list(range(c.n_scales)), frame_ids=c.frame_ids, height=c.H, width=c.W,
                                 min_depth=0.1, max_depth=100.0, disp_smoothness=1e-3, use_automasking=c.automask,
-                                batch=c.B, pose_type="separate", pose_frames="pair", fused=fused, noise="device")
+                                batch=c.B, pose_type="separate", pose_frames="pair", fused=fused, noise="device",
+                                fused_train=fused_train)
     st = types.SimpleNamespace(inv_projection={0: Depth2PointCloud(c.B, c.H, c.W)},
                                for_projection={0: PointCloud2Pixel(c.B, c.H, c.W)},
                                loss={"reprojection": ReprojectionLoss(), "edge_aware": SmoothLoss()})
@@ -46,11 +48,12 @@ def _setup(G, c, fused):
     return compute(opt, G.DEV), st, inputs, outputs
 
 
-@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("mode", ["train_kernel", "per_scale", "op_by_op"])
 @pytest.mark.parametrize("name", goldens.CASES)
-def test_compute_driver_vs_golden(G, name, fused):
+def test_compute_driver_vs_golden(G, name, mode):
     c = goldens.Case(name)
-    cp, st, inputs, outputs = _setup(G, c, fused)
+    fused = mode != "op_by_op"
+    cp, st, inputs, outputs = _setup(G, c, fused, fused_train=(mode == "train_kernel"))
     inputs, outputs = cp.image2warping(inputs, outputs, st)
     outputs = cp.compute_loss(inputs, outputs, st)
     outputs["loss"].backward()
