@@ -144,6 +144,52 @@ def cpu_baseline(batch=4, steps=3):
             "sample": "batch %d (configs[0]) x %d steps after 1 warm-up: torch-CPU nets + oracle loss path" % (batch, steps)}
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_command(n, argv, port=None):
+    """The command that starts n ranks of this script on this node (one process per GPU, RCCL rendezvous on 127.0.0.1)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+            "--master-addr", "127.0.0.1", "--master-port", str(port or free_port()), os.path.abspath(__file__)] + list(argv)
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without an external launcher: start N worker processes as CHILDREN -- before this
+    process has made any GPU call (torch.cuda.device_count() does not initialise the GPU; the process is never
+    replaced) -- relay rank 0's JSON line and return the children's exit code."""
+    import subprocess
+    rehearsal = os.environ.get("MDX_DIST_BACKEND", "nccl") != "nccl" or "--selftest-launcher" in argv
+    have = torch.cuda.device_count()
+    if n > have and not rehearsal:
+        sys.stderr.write("bench.py: --gpus %d asked for but this node exposes %d GPU(s); refusing to oversubscribe "
+                         "(MDX_DIST_BACKEND=gloo rehearses the launch path with several ranks on one GPU)\n" % (n, have))
+        return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    return subprocess.run(launch_command(n, argv), env=env).returncode
+
+
+def selftest_launcher(gpus):
+    """No GPU: every rank joins a gloo group and the rank count is verified by an all-reduce (tests/test_bench_launcher.py)."""
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:
+        torch.distributed.init_process_group("gloo")
+    ones = torch.ones(1)
+    if world > 1:
+        torch.distributed.all_reduce(ones)
+    if rank == 0:
+        print(json.dumps({"selftest": "launcher", "n_gpus": world, "ranks_verified": int(ones[0]), "asked": gpus}))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    return 0 if int(ones[0]) == gpus else 3
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -165,8 +211,16 @@ def main():
                          "training kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--selftest-launcher", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))        # nothing has touched the GPU yet
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%s -- start it as `python bench.py --gpus N` or under "
+                         "torch.distributed.run with --nproc-per-node N" % (args.gpus, os.environ.get("WORLD_SIZE", "1")))
+    if args.selftest_launcher:
+        raise SystemExit(selftest_launcher(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -262,10 +316,15 @@ def main():
             step()
         torch.cuda.synchronize()
         F.TIMING = None
+    ranks_verified = 1
     if world > 1:
-        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        tdev = device if os.environ.get("MDX_DIST_BACKEND", "nccl") == "nccl" else "cpu"
+        tmax = torch.tensor([dt], device=tdev, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax[0])
+        ones = torch.ones(1, device=tdev)
+        torch.distributed.all_reduce(ones)           # every rank really took part (RCCL when backend is nccl)
+        ranks_verified = int(ones[0])
     loss_val = float(loss.detach())
 
     if rank == 0:
@@ -281,7 +340,7 @@ def main():
                                       args.height, args.width, args.batch, args.num_layers, args.num_layers,
                                       str(frame_ids).replace(" ", ""), "fp32" if args.amp == "none" else "bf16 nets"),
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world},
-            "final_loss": loss_val, "hip_graph": bool(graph is not None), "miopen_find_db": bool(miopen_db),
+            "ranks_verified": ranks_verified, "final_loss": loss_val, "hip_graph": bool(graph is not None), "miopen_find_db": bool(miopen_db),
         }
         if not args.no_roofline and timing is not None:
             tsum = F.timing_summary(timing)

@@ -109,6 +109,11 @@ def ptr(t, dtype=torch.float32, optional=False):
         raise MdxError("mdx kernels run on the GPU only: got a %s tensor (no CPU fallback)" % t.device)
     if t.dtype != dtype or not t.is_contiguous():
         raise MdxError("expected contiguous %s, got %s contiguous=%s" % (dtype, t.dtype, t.is_contiguous()))
+    if t.device.index != torch.cuda.current_device():
+        # stream() hands the CURRENT device's stream to the library: kernels would run on that device with another
+        # device's pointers (a GPU memory fault, not an error code)
+        raise MdxError("tensor lives on %s but the current device is cuda:%d -- call torch.cuda.set_device / "
+                       "`with torch.cuda.device(...)` first" % (t.device, torch.cuda.current_device()))
     return C.c_void_p(t.data_ptr())
 
 

@@ -58,7 +58,9 @@ class DepthDecoder(nn.Module):
         self.sigmoid = nn.Sigmoid()
 
     def forward(self, input_features):
-        if input_features[-1].is_cuda and self._glue_ok():
+        # csrc/glue.hip puts B*C on a 16-bit grid axis: (far) larger batches take the torch op sequence below
+        if (input_features[-1].is_cuda and self._glue_ok()
+                and input_features[-1].shape[0] * 2 * max(f.shape[1] for f in input_features) <= 65535):
             return self._forward_glue(input_features)
         self.outputs = {}
         x = input_features[-1]

@@ -67,7 +67,9 @@ class BatchNorm2d(nn.BatchNorm2d):
         fused = (self.training and x.is_cuda and self.track_running_stats and self.momentum is not None
                  and self.affine and x.dtype in (torch.float32, torch.bfloat16) and x.dim() == 4
                  and torch.is_grad_enabled() and x.shape[0] % self._batch_groups == 0
-                 and x.shape[0] * x.shape[2] * x.shape[3] >= self.fused_min_elements)
+                 and x.shape[0] * x.shape[2] * x.shape[3] >= self.fused_min_elements
+                 # csrc/norm.hip puts (images of a group) x (8 K-element spans of a plane) on a 16-bit grid axis
+                 and (x.shape[0] // self._batch_groups) * ((x.shape[2] * x.shape[3] + 8191) // 8192) <= 65535)
         if not fused:
             out = self(x)
             if residual is not None:
@@ -217,7 +219,8 @@ class ResnetEncoder(nn.Module):
         x = (input_image - 0.45) / 0.225
         self.features.append(self.encoder.bn1.act(self.encoder.conv1(x)))
         stem = self.features[-1]
-        if stem.is_cuda and stem.dtype in (torch.float32, torch.bfloat16):
+        if (stem.is_cuda and stem.dtype in (torch.float32, torch.bfloat16)
+                and stem.shape[0] * stem.shape[1] <= 65535):         # csrc/glue.hip: B*C on a 16-bit grid axis
             from mdx import functional as F      # gather-based backward instead of ATen's atomics (csrc/glue.hip)
             pooled = F.maxpool3s2(stem)
         else:

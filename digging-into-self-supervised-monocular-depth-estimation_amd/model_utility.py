@@ -51,7 +51,7 @@ def read_velodyne_points(filename):
 
 def point2depth(calib_path, point_path, cam=2, vel_depth=False):
     """Projects a velodyne scan into camera `cam` -> sparse depth map [h, w] (model_utility.py:128-197).
-    Where several points fall on one pixel the nearest one wins (the reference's Counter loop, vectorised)."""
+    Where several points fall on one pixel the nearest one wins -- with the reference's own index arithmetic, see below."""
     cam2cam = read_calib(os.path.join(calib_path, "calib_cam_to_cam.txt"))
     velo2cam = read_calib(os.path.join(calib_path, "calib_velo_to_cam.txt"))
     velo2cam = np.hstack((velo2cam["R"].reshape(3, 3), velo2cam["T"][..., np.newaxis]))
@@ -73,16 +73,20 @@ def point2depth(calib_path, point_path, cam=2, vel_depth=False):
     pts = pts[ok]
     depth = np.zeros(tuple(im_shape[:2]))
     xs, ys = pts[:, 0].astype(np.int64), pts[:, 1].astype(np.int64)
-    # last write wins for unique pixels (as the reference's fancy-index assignment); duplicates -> minimum
-    depth[ys, xs] = pts[:, 2]
-    flat = ys * depth.shape[1] + xs
-    uniq, counts = np.unique(flat, return_counts=True)
-    dup = np.isin(flat, uniq[counts > 1])
-    if dup.any():
-        mins = np.full(depth.size, np.inf)
-        np.minimum.at(mins, flat[dup], pts[dup, 2])
-        sel = np.isfinite(mins)
-        depth.reshape(-1)[sel] = mins[sel]
+    depth[ys, xs] = pts[:, 2]        # several points on one pixel: the last one stands (numpy fancy assignment)
+    # The reference then walks the points that share a LINEAR INDEX (model_utility.py:187-194) and gives the pixel of
+    # the first of them the smallest depth of the group.  Its index is row*(n-1) + col - 1 (sub2ind, :119-124), not
+    # row*n + col: besides true duplicates, (row, 0) and (row-1, n-1) share an index -- then the first point's pixel
+    # receives the minimum over both pixels' points and the other pixel keeps its last-written value.  Reproduced as is
+    # (evaluation numbers are defined by it); vectorised: groups by np.unique, minimum per group, first member's pixel.
+    lin = pts[:, 1] * (depth.shape[1] - 1) + pts[:, 0] - 1
+    _, first, inverse, counts = np.unique(lin, return_index=True, return_inverse=True, return_counts=True)
+    inverse = inverse.reshape(-1)
+    if (counts > 1).any():
+        mins = np.full(len(counts), np.inf)
+        np.minimum.at(mins, inverse, pts[:, 2])
+        grp = np.flatnonzero(counts > 1)
+        depth[ys[first[grp]], xs[first[grp]]] = mins[grp]
     depth[depth < 0] = 0
     return depth
 

@@ -48,19 +48,34 @@ def main():
         i, out = cp.forward_depth(dict(inputs), outputs, s2)
         i, out = cp.forward_pose(i, out, s2)
         return cpu_compute_loss(o, i, out, seed=rank)
+    def check_grads():
+        worst = 0.0
+        for key in st.raw_model:
+            for (n1, p1), (n2, p2) in zip(st.raw_model[key].named_parameters(), local[key].named_parameters()):
+                if p1.grad is None:
+                    assert n1.startswith("encoder.fc."), (key, n1)
+                    continue
+                g = p2.grad.clone()
+                dist.all_reduce(g)
+                g /= world
+                worst = max(worst, float((p1.grad - g).abs().max() / (g.abs().max() + 1e-12)))
+        return worst
+    # 2b. the reference's per-pair pose loop (processor.py:61-83) calls the DDP-wrapped pose networks twice before one
+    #     backward: the reduced gradients must still be the mean over ranks of the local ones
+    cp.batch_pose_pairs = False
+    run(st.model).backward()
+    run(local).backward()
+    worst_pairs = check_grads()
+    assert worst_pairs < 1e-5, ("per-pair pose loop under DDP", worst_pairs)
+    for key in st.raw_model:
+        for m in (st.raw_model[key], local[key]):
+            for p in m.parameters():
+                p.grad = None
+    cp.batch_pose_pairs = True
     loss = run(st.model)
     loss.backward()
     run(local).backward()
-    worst = 0.0
-    for key in st.raw_model:
-        for (n1, p1), (n2, p2) in zip(st.raw_model[key].named_parameters(), local[key].named_parameters()):
-            if p1.grad is None:
-                assert n1.startswith("encoder.fc."), (key, n1)
-                continue
-            g = p2.grad.clone()
-            dist.all_reduce(g)
-            g /= world
-            worst = max(worst, float((p1.grad - g).abs().max() / (g.abs().max() + 1e-12)))
+    worst = check_grads()
     assert worst < 1e-5, worst
     # 3. after the step every rank holds the same parameters
     st.optim["optimizer"].step()

@@ -157,7 +157,11 @@ def test_miopen_find_db_install(tmp_path, monkeypatch):
     monkeypatch.delenv("MIOPEN_USER_DB_PATH", raising=False)
     monkeypatch.setattr(tempfile, "tempdir", str(tmp_path))
     d = tuning.install_miopen_db(rank=3)
-    assert d.endswith("_r3") and os.environ["MIOPEN_USER_DB_PATH"] == d
+    assert "_r3_" in os.path.basename(d) and os.environ["MIOPEN_USER_DB_PATH"] == d
+    monkeypatch.delenv("MIOPEN_USER_DB_PATH")
+    d2 = tuning.install_miopen_db(rank=3)                   # a second job with the same rank: its own directory
+    assert d2 != d and sorted(os.listdir(d2)) == sorted(os.listdir(d))
+    monkeypatch.setenv("MIOPEN_USER_DB_PATH", d)
     shipped = sorted(f for f in os.listdir(os.path.join(tuning.PACKAGE_DIR, "miopen_db")) if f.endswith(".txt"))
     assert shipped and sorted(os.listdir(d)) == shipped
     for name in shipped:   # MIOpen's text format: one "key=value" record per line, keyed by gfx950
@@ -168,6 +172,11 @@ def test_miopen_find_db_install(tmp_path, monkeypatch):
     monkeypatch.delenv("MIOPEN_USER_DB_PATH")
     monkeypatch.setenv("MDX_MIOPEN_DB", "0")
     assert tuning.install_miopen_db(rank=0) is None and "MIOPEN_USER_DB_PATH" not in os.environ
+    # another MIOpen build than the one the db was recorded with: warn, report "no db" (MIOpen would ignore the files)
+    monkeypatch.delenv("MDX_MIOPEN_DB")
+    monkeypatch.setattr(tuning, "miopen_db_tag", lambda: "9_9_9_20990101-1-1-gdeadbeef00")
+    with pytest.warns(UserWarning, match="another MIOpen build"):
+        assert tuning.install_miopen_db(rank=0) is None
 
 
 def test_batchnorm_host_counter_keeps_state_dict_contract():
