@@ -190,6 +190,39 @@ def selftest_launcher(gpus):
     return 0 if int(ones[0]) == gpus else 3
 
 
+def trainer_loop(args, frame_ids, steps, warmup, workers):
+    """The loop people run (model_train.trainer): batches from the DataLoader (worker processes, pinned memory, uploaded
+    one step ahead on a side stream), train_step, and control.metric on every step -- beside the resident-input figure."""
+    from model_train import trainer
+    opt = make_opt(args.batch, height=args.height, width=args.width, frame_ids=frame_ids, num_layers=args.num_layers,
+                   amp=args.amp, workers=workers)
+    opt.fused_train = not args.per_scale_kernels
+    opt.synthetic_length = (steps + warmup + 4) * args.batch * int(os.environ.get("WORLD_SIZE", "1"))
+    opt.synthetic_pool = 4 * args.batch          # the stand-in dataset must not be what is measured
+    opt.uint8_loader = not args.float_loader     # colours uint8 through the host pipeline, x/255 on the GPU
+    opt.collate_step_keys = not args.float_loader
+    opt.max_steps, opt.miopen_find = 0, args.miopen_find
+    tr = trainer(opt)
+    tr.setting.set_train()
+    log = {k: [] for k in tr.control.metric_name}
+    it = iter(tr.batches(tr.setting.train_dataloader))
+    for _ in range(warmup):
+        b = next(it)
+        log = tr.control.metric(b, tr.train_step(b), log)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        b = next(it)
+        log = tr.control.metric(b, tr.train_step(b), log)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    vals = {k: tr.control._mean(v) for k, v in log.items()}
+    del it
+    return {"value": args.batch * steps / dt, "unit": "images/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
+            "workers": workers, "uint8_loader": bool(opt.uint8_loader), "what": "model_train.trainer: DataLoader (pinned, side-stream upload) -> train_step -> "
+                                        "control.metric every step", "abs_rel_monitor": vals.get("abs_rel")}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -209,6 +242,11 @@ def main():
     ap.add_argument("--per-scale-kernels", action="store_true",
                     help="round-1 path: one fused forward + one backward kernel per scale instead of the one-launch "
                          "training kernel")
+    ap.add_argument("--no-trainer-loop", action="store_true",
+                    help="skip the second measurement (the DataLoader-fed trainer loop, reported as trainer_loop)")
+    ap.add_argument("--float-loader", action="store_true",
+                    help="trainer loop with the reference's float32 colours through the DataLoader (4x the host bytes)")
+    ap.add_argument("--workers", type=int, default=12, help="DataLoader workers of the trainer-loop measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--selftest-launcher", action="store_true", help=argparse.SUPPRESS)
@@ -391,6 +429,11 @@ def main():
                 line["roofline_other"] = [{"kernel": k[n]["name"], "achieved": k[n]["GBs"], "frac": k[n]["GBs"] / HBM_PEAK_GBS,
                                            "launch_us": 1e3 * k[n]["ms"], "alg_bytes_per_launch": k[n]["bytes"]}
                                           for n in others]
+        if not args.no_trainer_loop and world == 1 and graph is None:
+            del st, cp, inputs, optim
+            torch.cuda.empty_cache()
+            line["trainer_loop"] = trainer_loop(args, frame_ids, args.steps, args.warmup, args.workers)
+            line["trainer_loop"]["vs_resident"] = line["trainer_loop"]["value"] / line["value"]
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))

@@ -26,8 +26,12 @@ SIDE_MAP = {"2": 2, "3": 3, "l": 2, "r": 3}
 K_NORM = np.array([[0.58, 0, 0.5, 0], [0, 1.92, 0.5, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=np.float32)
 
 
-def to_tensor(img):
-    return torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).float().div_(255.0)
+def to_tensor(img, uint8=False):
+    """ToTensor: [3,H,W] float32 in [0,1] (x / 255).  uint8=True leaves the division to the consumer
+    (compute.forward_depth does it on the GPU, same correctly rounded x / 255): a quarter of the bytes go through the
+    worker -> shared memory -> pinned memory -> PCIe pipeline."""
+    t = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1)
+    return t.contiguous() if uint8 else t.float().div_(255.0)
 
 
 class ColorJitter(object):
@@ -55,13 +59,14 @@ class ColorJitter(object):
 
 class KITTIDataset(Dataset):
     def __init__(self, datapath, filename, is_training, frame_ids, height=192, width=640, ext=".jpg", scale=4,
-                 k_mode="reference_mono", gt_size=(375, 1242), load_depth=True):
+                 k_mode="reference_mono", gt_size=(375, 1242), load_depth=True, uint8=False):
         if height % 32 != 0 or width % 32 != 0:
             raise ValueError("(H, W) must be multiples of 32; KITTI sizes are (192, 640) or (320, 1024)")
         self.datapath, self.filename, self.is_training = datapath, list(filename), is_training
         self.frame_ids, self.height, self.width = list(frame_ids), height, width
         self.ext = ext if ext.startswith(".") else "." + ext
         self.scale, self.k_mode, self.gt_size, self.load_depth = scale, k_mode, gt_size, load_depth
+        self.uint8 = uint8
 
     def __len__(self):
         return len(self.filename)
@@ -109,8 +114,8 @@ class KITTIDataset(Dataset):
                 image = self.load_image(folder, key_frame + frame_id, side, do_flip)
             for s in range(self.scale):
                 small = image.resize((self.width // (2 ** s), self.height // (2 ** s)), Image.LANCZOS)
-                out[("color", frame_id, s)] = to_tensor(small)
-                out[("color_aug", frame_id, s)] = to_tensor(jitter(small))
+                out[("color", frame_id, s)] = to_tensor(small, self.uint8)
+                out[("color_aug", frame_id, s)] = to_tensor(jitter(small), self.uint8)
         if self.load_depth:
             out[("depth", 0)] = self.load_point(folder, key_frame, side, do_flip)
         for s in range(self.scale):

@@ -29,19 +29,75 @@ def compute_depth_error(ground_truth, prediction, lib="numpy"):
     raise ValueError("lib arg is 'numpy' or 'torch'")
 
 
+# Share of the Garg-crop window the train-time monitor's fixed-size buffer holds (compute_depth_metric).  Velodyne
+# ground truth (point2depth) covers ~7 % of the window; denser ground truth (e.g. the KITTI depth-benchmark maps) needs
+# a larger share -- 1.0 always fits.  More valid pixels than the buffer holds -> the metrics read NaN.
+METRIC_CAPACITY = 1.0 / 6.0
+
+
+def _masked_errors(gt, pred, valid, count):
+    """compute_depth_error's seven numbers over the entries where `valid`, on fixed-size tensors (count = valid.sum())."""
+    zero, one = torch.zeros_like(gt), torch.ones_like(gt)
+    g, p = torch.where(valid, gt, one), torch.where(valid, pred, one)       # harmless values in the padding
+    cnt = count.to(gt.dtype)
+
+    def mean(x):
+        return torch.where(valid, x, zero).sum() / cnt
+    threshold = torch.maximum(g / p, p / g)
+    a1, a2, a3 = (mean((threshold < 1.25 ** k).to(gt.dtype)) for k in (1, 2, 3))
+    rmse = torch.sqrt(mean((g - p) ** 2))
+    rmse_log = torch.sqrt(mean((torch.log(g) - torch.log(p)) ** 2))
+    abs_rel = mean(torch.abs(g - p) / g)
+    sq_rel = mean((g - p) ** 2 / g)
+    return abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3
+
+
+def _lower_median(values, valid, count):
+    """torch.median of the valid entries (the lower of the two middle values for an even count), no host sync:
+    padding sorts to the end as +inf, the rank is read with a device-side index."""
+    s, _ = torch.sort(torch.where(valid, values, torch.full_like(values, float("inf"))))
+    k = torch.clamp((count - 1) // 2, min=0, max=values.numel() - 1).reshape(1)
+    return s.gather(0, k)[0]
+
+
 def compute_depth_metric(inputs, outputs, lib="torch"):
     """reference: model_metric.py:70-105.  Train-time monitor: bilinear to the ground-truth size,
     Garg crop (the reference hard-codes 375x1242 -> rows 153:371, cols 44:1197), batch-level median
-    scaling, clamp to [1e-3, 80].  Stays on the device; no host sync here."""
+    scaling, clamp to [1e-3, 80].
+
+    The reference gathers the masked pixels with boolean indexing (`gt[mask]`): a data-dependent shape, i.e. a
+    device -> host synchronisation in every training step.  Here the masked pixels are compacted into a FIXED-size
+    buffer (torch.nonzero_static over the crop window; the lidar ground truth covers ~7 % of it, the buffer holds a
+    sixth) and every statistic is a masked reduction over that buffer: same numbers, nothing leaves the device.  If
+    more pixels are valid than the buffer holds the metrics come out as NaN (visible in the log, never silently wrong).
+    """
     gt = inputs[("depth", 0)]
     gh, gw = gt.shape[-2:]
     pred = outputs[("depth", 0, 0)].detach()
     pred = torch.clamp(TF.interpolate(pred, [gh, gw], mode="bilinear", align_corners=False), 1e-3, 80)
-    mask = gt > 0
-    crop = torch.zeros_like(mask)
-    crop[:, :, int(0.40810811 * gh):int(0.99189189 * gh), int(0.03594771 * gw):int(0.96405229 * gw)] = 1
-    mask = mask * crop
-    gt_m, pred_m = gt[mask], pred[mask]
-    pred_m = pred_m * (torch.median(gt_m) / torch.median(pred_m))
+    r0, r1 = int(0.40810811 * gh), int(0.99189189 * gh)
+    c0, c1 = int(0.03594771 * gw), int(0.96405229 * gw)
+    if not hasattr(torch, "nonzero_static"):
+        mask = gt > 0
+        crop = torch.zeros_like(mask)
+        crop[:, :, r0:r1, c0:c1] = 1
+        mask = mask * crop
+        gt_m, pred_m = gt[mask], pred[mask]
+        pred_m = pred_m * (torch.median(gt_m) / torch.median(pred_m))
+        pred_m = torch.clamp(pred_m, min=1e-3, max=80)
+        return compute_depth_error(ground_truth=gt_m, prediction=pred_m, lib=lib)
+    # mask = (gt > 0) * crop  ==  (gt > 0) inside the crop window: everything below works on the window only
+    gt_c = gt[:, :, r0:r1, c0:c1].reshape(-1)
+    pred_c = pred[:, :, r0:r1, c0:c1].reshape(-1)
+    flat = gt_c > 0
+    cap = min(flat.numel(), max(1024, int(flat.numel() * METRIC_CAPACITY)))
+    count = flat.sum()
+    idx = torch.nonzero_static(flat, size=cap, fill_value=flat.numel()).reshape(-1)
+    valid = idx < flat.numel()
+    idx = torch.clamp(idx, max=flat.numel() - 1)
+    gt_m, pred_m = gt_c[idx], pred_c[idx]
+    pred_m = pred_m * (_lower_median(gt_m, valid, count) / _lower_median(pred_m, valid, count))
     pred_m = torch.clamp(pred_m, min=1e-3, max=80)
-    return compute_depth_error(ground_truth=gt_m, prediction=pred_m, lib=lib)
+    errs = _masked_errors(gt_m, pred_m, valid, count)
+    overflow = count > cap
+    return tuple(torch.where(overflow, torch.full_like(e, float("nan")), e) for e in errs)

@@ -34,6 +34,15 @@ def options(argv=None):
     p.add_argument("--use_automasking", type=lambda s: str(s).lower() in ("1", "true", "yes"), default=True)
     # additions
     p.add_argument("--fused", type=lambda s: str(s).lower() in ("1", "true", "yes"), default=True)
+    p.add_argument("--fused_train", type=lambda s: str(s).lower() in ("1", "true", "yes"), default=True,
+                   help="one launch for every scale's photometric term and its gradient (csrc/photo_train.hip)")
+    p.add_argument("--uint8_loader", type=lambda s: str(s).lower() in ("1", "true", "yes"), default=True,
+                   help="colours stay uint8 through the DataLoader; x/255 happens on the GPU (same values, 1/4 of the bytes)")
+    p.add_argument("--collate_step_keys", type=lambda s: str(s).lower() in ("1", "true", "yes"), default=True,
+                   help="DataLoader workers stack only the entries a step reads")
+    p.add_argument("--device_prefetch", type=lambda s: str(s).lower() in ("1", "true", "yes"), default=True,
+                   help="upload the next batch on a side stream while the current step computes")
+    p.add_argument("--synthetic_pool", type=int, default=0, help="synthetic dataset: number of distinct samples kept (0 = all)")
     p.add_argument("--noise", type=str, default="device", choices=["device", "cpu"])
     p.add_argument("--amp", type=str, default="none", choices=["none", "bf16"])
     p.add_argument("--channels_last", action="store_true")

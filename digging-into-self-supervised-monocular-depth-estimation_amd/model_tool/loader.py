@@ -17,6 +17,14 @@ def _opt(opt, name, default):
     return getattr(opt, name, default)
 
 
+def collate_step_keys(samples):
+    """default_collate over the entries a step reads only (model_tool.processor.step_reads): the workers do not stack,
+    and the pinning thread does not copy, what nothing consumes."""
+    from torch.utils.data import default_collate
+    from .processor import step_reads
+    return default_collate([{k: v for k, v in s.items() if step_reads(k)} for s in samples])
+
+
 class setting(object):
     def __init__(self, opt, device):
         self.opt = opt
@@ -43,19 +51,24 @@ class setting(object):
         if opt.dataset == "synthetic":
             length = _opt(opt, "synthetic_length", 64 * opt.batch) if is_training else 4 * opt.batch
             dataset = SyntheticKITTI(length, opt.frame_ids, opt.height, opt.width, len(opt.scales),
-                                     seed=0 if is_training else 1)
+                                     seed=0 if is_training else 1, pool=_opt(opt, "synthetic_pool", 0),
+                                     uint8=_opt(opt, "uint8_loader", False))
         else:
             from model_loader import KITTIMonoDataset_v2, KITTIMonoStereoDataset
             from model_utility import readlines
             names = readlines(os.path.join(opt.splits, opt.datatype, "{}_files.txt".format(split)))
             cls = KITTIMonoDataset_v2 if opt.dataset == "kitti_mono" else KITTIMonoStereoDataset
             dataset = cls(opt.datapath, names, is_training, opt.frame_ids, opt.height, opt.width, ".jpg", len(opt.scales))
+            dataset.uint8 = _opt(opt, "uint8_loader", False)
         sampler = None
         if self.distributed:
             sampler = DistributedSampler(dataset, self.world_size, self.rank, shuffle=shuffle, drop_last=True)
             shuffle = False
-        return DataLoader(dataset, opt.batch, shuffle, sampler=sampler, num_workers=opt.num_workers,
-                          drop_last=True, pin_memory=str(self.device).startswith("cuda"))
+        workers = opt.num_workers
+        return DataLoader(dataset, opt.batch, shuffle, sampler=sampler, num_workers=workers,
+                          drop_last=True, pin_memory=str(self.device).startswith("cuda"),
+                          collate_fn=collate_step_keys if _opt(opt, "collate_step_keys", False) else None,
+                          persistent_workers=workers > 0, prefetch_factor=(_opt(opt, "prefetch_factor", 4) if workers > 0 else None))
 
     # reference: loader.py:70-96
     def set_model(self):

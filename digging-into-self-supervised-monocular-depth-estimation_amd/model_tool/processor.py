@@ -22,6 +22,22 @@ def _opt(opt, name, default):
     return getattr(opt, name, default)
 
 
+def step_reads(key):
+    """The entries of the data layer's dictionary a step consumes.  The reference collates and copies
+    every key to the device (processor.py:34-35); the colour_aug pyramids, the source frames' pyramids and the
+    intrinsics of scales 1-3 are never read: they are neither uploaded (forward_depth) nor, with
+    opt.collate_step_keys, stacked into the batch by the DataLoader workers."""
+    if not isinstance(key, tuple):
+        return True                                         # "stereo"
+    if key[0] == "color":
+        return key[2] == 0 or key[1] == 0                   # warp sources / identity / target; target pyramid (smoothness)
+    if key[0] == "color_aug":
+        return key[2] == 0                                  # network inputs
+    if key[0] in ("K", "inv_K"):
+        return key[1] == 0
+    return True                                             # ("depth", 0), injected test entries
+
+
 class compute(object):
     def __init__(self, opt, device):
         self.opt = opt
@@ -41,10 +57,18 @@ class compute(object):
         enabled = self.amp == "bf16" and str(self.device).startswith("cuda")
         return torch.autocast(device_type="cuda", dtype=torch.bfloat16, enabled=enabled)
 
+    def _step_reads(self, key):
+        return step_reads(key)
+
     def forward_depth(self, inputs, outputs, setting):
+        dev = torch.device(self.device)
         for key in inputs:
-            if torch.is_tensor(inputs[key]) and inputs[key].device != torch.device(self.device):
+            if torch.is_tensor(inputs[key]) and inputs[key].device != dev and self._step_reads(key):
                 inputs[key] = inputs[key].to(self.device, non_blocking=True)
+            # uint8 colours (opt.uint8_loader): ToTensor's x / 255 happens here, on the device -- bit-identical
+            if (torch.is_tensor(inputs[key]) and inputs[key].dtype == torch.uint8 and isinstance(key, tuple)
+                    and key[0] in ("color", "color_aug") and inputs[key].device == dev):
+                inputs[key] = inputs[key].float().div_(255.0)
         with self._autocast():
             if self.opt.pose_type == "shared":
                 all_frames = torch.cat([inputs[("color_aug", f, 0)] for f in self.opt.frame_ids])

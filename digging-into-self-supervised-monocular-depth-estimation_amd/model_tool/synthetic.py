@@ -15,15 +15,27 @@ def make_K(height, width):
 
 
 class SyntheticKITTI(Dataset):
-    def __init__(self, length, frame_ids, height, width, num_scales=4, seed=0, gt_size=(375, 1242)):
+    def __init__(self, length, frame_ids, height, width, num_scales=4, seed=0, gt_size=(375, 1242), pool=0, uint8=False):
+        """pool > 0: only `pool` distinct samples are ever generated (index modulo pool) and they are kept -- the
+        generator below costs ~20 ms per sample, far more than decoding a KITTI frame; a throughput measurement of the
+        training LOOP must not be a measurement of this stand-in."""
         self.length, self.frame_ids = length, list(frame_ids)
         self.height, self.width, self.num_scales = height, width, num_scales
-        self.seed, self.gt_size = seed, gt_size
+        self.seed, self.gt_size, self.pool, self._cache = seed, gt_size, pool, {}
+        self.uint8 = uint8                    # colours as uint8 (x 255), as model_loader.kitti with uint8=True
 
     def __len__(self):
         return self.length
 
     def __getitem__(self, index):
+        if self.pool:
+            index = index % self.pool
+            if index not in self._cache:
+                self._cache[index] = self._make(index)
+            return dict(self._cache[index])
+        return self._make(index)
+
+    def _make(self, index):
         g = torch.Generator().manual_seed(self.seed * 1000003 + index)
         inputs = {}
         base = torch.rand(3, self.height // 8, self.width // 8, generator=g)
@@ -35,6 +47,8 @@ class SyntheticKITTI(Dataset):
             img = img.clamp(0, 1)
             for s in range(self.num_scales):
                 im = img if s == 0 else torch.nn.functional.avg_pool2d(img[None], 2 ** s)[0]
+                if self.uint8:
+                    im = (im * 255).round().to(torch.uint8)
                 inputs[("color", f, s)] = im
                 inputs[("color_aug", f, s)] = im
         K, invK = make_K(self.height, self.width)

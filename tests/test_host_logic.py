@@ -108,7 +108,14 @@ def test_depth_metrics():
     inputs = {("depth", 0): torch.zeros(2, 1, 375, 1242)}
     inputs[("depth", 0)][:, :, 200:300, 100:1100] = 10.0
     outputs = {("depth", 0, 0): torch.full((2, 1, 192, 640), 5.0)}
-    m = model_loss.compute_depth_metric(inputs, outputs, "torch")
+    import model_loss.model_metric as mm
+    # 40 % of the crop window is valid here: more than the monitor's fixed-size buffer holds by default -> NaN, loudly
+    assert all(np.isnan(float(v)) for v in model_loss.compute_depth_metric(inputs, outputs, "torch"))
+    keep, mm.METRIC_CAPACITY = mm.METRIC_CAPACITY, 1.0
+    try:
+        m = model_loss.compute_depth_metric(inputs, outputs, "torch")
+    finally:
+        mm.METRIC_CAPACITY = keep
     assert float(m[0]) < 1e-6   # median scaling removes the factor 2
 
 

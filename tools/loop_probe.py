@@ -1,0 +1,50 @@
+"""Where the DataLoader-fed training loop loses time against the resident-input step: each piece timed in isolation."""
+import importlib, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+bench = importlib.import_module("bench")
+pkg = importlib.import_module("digging-into-self-supervised-monocular-depth-estimation_amd")
+pkg.install_miopen_db(0)
+from model_train import trainer
+
+workers = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+opt = bench.make_opt(12, workers=workers)
+opt.synthetic_length, opt.synthetic_pool, opt.max_steps, opt.miopen_find = 120 * 12, 48, 0, False
+opt.uint8_loader = (os.environ.get('FLOAT_LOADER') is None)
+tr = trainer(opt)
+tr.setting.set_train()
+N = 25
+
+
+def timed(name, fn, n=N):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    print("%-46s %7.2f ms/step" % (name, 1e3 * (time.perf_counter() - t0) / n), flush=True)
+
+
+it = iter(tr.setting.train_dataloader)
+for _ in range(3):
+    next(it)
+timed("DataLoader alone (pinned batches, no GPU)", lambda: next(it))
+b = next(it)
+dev = {k: (v.to(tr.device) if torch.is_tensor(v) else v) for k, v in b.items()}
+for _ in range(5):
+    tr.train_step(dev)
+timed("train_step, resident batch", lambda: tr.train_step(dev))
+log = {k: [] for k in tr.control.metric_name}
+out = tr.train_step(dev)
+timed("control.metric alone", lambda: tr.control.metric(dev, out, log))
+timed("train_step + metric, resident batch", lambda: tr.control.metric(dev, tr.train_step(dev), log))
+wanted = tr.compute._step_reads
+timed("upload of one pinned batch (wanted keys)", lambda: {k: v.to(tr.device, non_blocking=True) for k, v in b.items() if torch.is_tensor(v) and wanted(k)})
+pit = iter(tr.batches(tr.setting.train_dataloader))
+for _ in range(3):
+    next(pit)
+timed("prefetcher alone (loader + side-stream upload)", lambda: next(pit))
+def full():
+    bb = next(pit)
+    tr.control.metric(bb, tr.train_step(bb), log)
+timed("full loop", full)
