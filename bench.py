@@ -63,8 +63,10 @@ def alg_bytes(B, H, W, S, scale, bwd=False):
     return B * H * W * (12 + 12 * S + 1) + n_lo * (8 if bwd else 4)
 
 
-def cpu_baseline(batch=4, steps=3):
-    """The same training step on the host: torch-CPU networks + the CPU oracle for the loss path."""
+def cpu_baseline(batch=4, steps=10):
+    """The same training step on the host: torch-CPU networks + the CPU oracle for the loss path (10 timed steps of
+    batch 4, ~10-20 s), and -- SURVEY 8d's two loss-path lines -- the loss path alone (forward + backward, networks
+    excluded) through the oracle and through the plain-PyTorch composite of tests/torch_composite.py."""
     from oracle import oracle as orc
     from model_layer import ResnetEncoder, DepthDecoder, PoseDecoder, param2matrix
     from model_tool.synthetic import SyntheticKITTI
@@ -140,8 +142,36 @@ def cpu_baseline(batch=4, steps=3):
         loss.backward()
         optim.step()
     dt = time.perf_counter() - t0
-    return {"value": batch * steps / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "batch %d (configs[0]) x %d steps after 1 warm-up: torch-CPU nets + oracle loss path" % (batch, steps)}
+    out = {"value": batch * steps / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": "batch %d (configs[0]) x %d steps after 1 warm-up: torch-CPU nets + oracle loss path" % (batch, steps)}
+    # the loss path alone, forward + backward, on fixed network outputs
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch_composite as tc
+    dd = {s: disps[("disp", s)].detach().clone().requires_grad_(True) for s in range(4)}
+    Tm = [torch.eye(4).repeat(batch, 1, 1).requires_grad_(True) for _ in range(S)]
+    colors = {s: inputs[("color", 0, s)] for s in range(4)}
+    srcs_t = [inputs[("color", f, 0)] for f in (-1, 1)]
+    Kt, invKt = inputs[("K", 0)], inputs[("inv_K", 0)]
+
+    def run_composite():
+        loss, _ = tc.loss_path(dd, colors, srcs_t, Kt, invKt, Tm)
+        loss.backward()
+
+    def run_oracle():
+        Pm = torch.stack([torch.matmul(Kt, T)[:, :3, :] for T in Tm])
+        loss = 0
+        for s in range(4):
+            noise = rng.randn(batch, S, H, W).astype(np.float32)
+            loss = loss + OracleScale.apply(dd[s], Pm, noise) + 1e-3 * OracleSmooth.apply(dd[s], colors[s]) / (2 ** s)
+        (loss / 4).backward()
+    for name, fn, reps in (("torch_composite", run_composite, 4), ("oracle", run_oracle, 6)):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        out["loss_path_" + name] = {"value": batch * reps / (time.perf_counter() - t0), "unit": "images/s",
+                                    "sample": "loss path only (4 scales, forward + backward), batch %d x %d" % (batch, reps)}
+    return out
 
 
 def free_port():

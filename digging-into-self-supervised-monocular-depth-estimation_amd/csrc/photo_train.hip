@@ -584,16 +584,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S <= 2 ? 3 :
 
 // ---------------------------------------------------------------------------------------------
 // Second pass, ONE launch, fixed summation orders (deterministic):
-//   * transpose of the bilinear upsample (autograd of warp.py:18-20) of every scale below full resolution:
-//     LPO lanes share one low-resolution pixel, each takes every LPO-th row of its footprint (x weights of the
-//     footprint in registers), a shuffle tree adds them;
+//   * transpose of the bilinear upsample (autograd of warp.py:18-20) of every scale below full resolution with an
+//     integer ratio R in {2, 4, 8}: a block owns a tile of TH x TW low-resolution pixels, stages the full-resolution
+//     gradient region their footprints cover in LDS with coalesced 16-byte loads, forms the x / y weights of the
+//     tile once (up_tap: the forward's own tap arithmetic, so borders are exact) and then every pixel sums its
+//     (2R+4)^2 footprint out of LDS (LPO lanes per pixel split the rows, a shuffle tree adds them).  Gathering the
+//     footprints straight from global memory cost ~40 CU-cycles per load instruction (every lane another cache line);
 //   * d(P)[scale][f][b][k] = sum over the items of (scale, b) -- one wave64 per output;
 //   * loss_sum[scale].
 // ---------------------------------------------------------------------------------------------
 struct FinishArgs {
     const float *gup[MDX_MAX_SCALES];
     float *gin[MDX_MAX_SCALES];
-    int h[MDX_MAX_SCALES], w[MDX_MAX_SCALES];
+    int h[MDX_MAX_SCALES], w[MDX_MAX_SCALES], ratio[MDX_MAX_SCALES], tiles_x[MDX_MAX_SCALES], tiles_y[MDX_MAX_SCALES];
     int up_first[MDX_MAX_SCALES + 1];   // first block of each scale's upsample job (equal = no job)
     int B, H, W, nscales, S, ipi;
     const float *partP;
@@ -602,90 +605,112 @@ struct FinishArgs {
 };
 
 // first / last output index whose bilinear source index scale*(dst+0.5)-0.5 can fall in (i-1, i+1), with a margin of
-// one (the weights decide; the margin only has to cover the rounding of this estimate)
+// one (the weights decide; the margin only has to cover the rounding of this estimate).  For an even integer ratio R
+// these are R*i - R/2 - 2 and R*i + 3R/2 + 1: a footprint of 2R + 4 taps.
 MDX_DEV int foot_lo(int i, float inv_scale) { return (int)floorf(((float)i - 0.5f) * inv_scale - 0.5f) - 1; }
 MDX_DEV int foot_hi(int i, float inv_scale) { return (int)ceilf(((float)i + 1.5f) * inv_scale - 0.5f) + 1; }
 
-template <int NW, int LPO>
-MDX_DEV void upsample_bwd_body(const float *__restrict__ gout, int BC, int H, int W, float *__restrict__ gin, int h,
-                               int w, unsigned block, float *s_wx)
+constexpr int FIN_LDS_FLOATS = 44 * 144 + 64 * 20 + 4 * 20;     // largest configuration (R = 8)
+
+template <int R, int TW, int TH, int LPO>
+MDX_DEV void upsample_bwd_tile(const float *__restrict__ gout, int H, int W, float *__restrict__ gin, int h, int w,
+                               int bc, int tile_x, int tile_y, float *lds)
 {
-    constexpr int NOUT = NT / LPO;            // low-resolution pixels per block
-    const size_t n = (size_t)BC * h * w;
+    constexpr int NT_ = 2 * R + 4;                       // taps per axis
+    constexpr int NR = R * TH + R + 4;                   // region rows
+    constexpr int NC = ((R * TW + R + 4 + 3 + 3) / 4) * 4;   // region columns: + up to 3 for the 16-byte alignment
+    static_assert(NR * NC + TW * NT_ + TH * NT_ <= FIN_LDS_FLOATS, "LDS");
+    static_assert(TW * TH * LPO == NT, "one lane group per pixel");
+    float *s_g = lds, *s_wx = lds + NR * NC, *s_wy = s_wx + TW * NT_;
+    const int tid = threadIdx.x;
+    const int jx0 = tile_x * TW, iy0 = tile_y * TH;
     const float sy = (float)h / (float)H, sx = (float)w / (float)W;
-    const float isy = (float)H / (float)h, isx = (float)W / (float)w;
-    // x weights of the block's pixels, computed once per block (every lane of a pixel, and every row, shares them)
-    for (int e = threadIdx.x; e < NOUT * NW; e += NT) {
-        const int oo = e / NW, t = e - oo * NW;
-        const size_t o2 = min((size_t)block * NOUT + oo, n - 1);
-        const int jx2 = (int)(o2 % w);
-        const int xa2 = max(0, foot_lo(jx2, isx)), xb2 = min(W - 1, foot_hi(jx2, isx));
-        const int x = xa2 + t;
-        const UpTap tx = up_tap(sx, x <= xb2 ? x : xb2, w);
-        s_wx[e] = x <= xb2 ? (tx.i0 == jx2 ? tx.l0 : 0.f) + (tx.i1 == jx2 ? tx.l1 : 0.f) : 0.f;
+    const int ys = R * iy0 - R / 2 - 2;                  // region origin (may lie outside the image: zeros)
+    const int xs = (R * jx0 - R / 2 - 2) & ~3;           // aligned down to 4 columns (arithmetic on negatives is fine: two's complement)
+    const float *g = gout + (size_t)bc * H * W;
+    // ---- stage the region: 16-byte loads where the four columns are inside the image, scalars at its edges ----
+    const bool vec = (W & 3) == 0;
+    for (int e = tid; e < NR * (NC / 4); e += NT) {
+        const int rr = e / (NC / 4), c4 = (e - rr * (NC / 4)) * 4;
+        const int y = ys + rr, x = xs + c4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (y >= 0 && y < H) {
+            if (vec && x >= 0 && x + 3 < W) {
+                v = *reinterpret_cast<const float4 *>(g + (size_t)y * W + x);
+            } else {
+                const float *row = g + (size_t)y * W;
+                v.x = (x >= 0 && x < W) ? row[x] : 0.f;
+                v.y = (x + 1 >= 0 && x + 1 < W) ? row[x + 1] : 0.f;
+                v.z = (x + 2 >= 0 && x + 2 < W) ? row[x + 2] : 0.f;
+                v.w = (x + 3 >= 0 && x + 3 < W) ? row[x + 3] : 0.f;
+            }
+        }
+        *reinterpret_cast<float4 *>(s_g + rr * NC + c4) = v;
+    }
+    // ---- weights of the tile's columns and rows (zero for taps outside the image or not touching the pixel) ----
+    for (int e = tid; e < TW * NT_ + TH * NT_; e += NT) {
+        const bool isx = e < TW * NT_;
+        const int ee = isx ? e : e - TW * NT_;
+        const int p = ee / NT_, t = ee - p * NT_;
+        const int i = (isx ? jx0 : iy0) + p, n_in = isx ? w : h, n_out = isx ? W : H;
+        const int pos = R * i - R / 2 - 2 + t;           // full-resolution index of tap t
+        float wgt = 0.f;
+        if (i < n_in && pos >= 0 && pos < n_out) {
+            const UpTap tp = up_tap(isx ? sx : sy, pos, n_in);
+            wgt = (tp.i0 == i ? tp.l0 : 0.f) + (tp.i1 == i ? tp.l1 : 0.f);
+        }
+        (isx ? s_wx : s_wy)[ee] = wgt;
     }
     __syncthreads();
-    const int oo = threadIdx.x / LPO, l = threadIdx.x % LPO;
-    const size_t oraw = (size_t)block * NOUT + oo;
-    const size_t o = min(oraw, n - 1);
-    const int jx = (int)(o % w), iy = (int)((o / w) % h);
-    const size_t bc = o / ((size_t)w * h);
-    const int ya = max(0, foot_lo(iy, isy)), yb = min(H - 1, foot_hi(iy, isy));
-    const int xa = max(0, foot_lo(jx, isx));
-    const float *g = gout + bc * (size_t)H * W;
-    // a lane's rows: ya + l, ya + l + LPO, ...; the footprint has at most NW rows, so NIT rounds cover it.  All loads
-    // of all rounds are issued before the first is consumed (one memory round trip per pixel instead of one per row).
-    constexpr int NIT = (NW + LPO - 1) / LPO;
-    float v[NIT][NW], wy[NIT];
+    // ---- footprint sums ----
+    const int l = tid % LPO, pix = tid / LPO;
+    const int jj = pix % TW, ii = pix / TW;
+    const int c0 = R * (jx0 + jj) - R / 2 - 2 - xs;      // region column of tap 0
+    float wxr[NT_];
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int y = ya + l + it * LPO;
-        const int yc = min(y, yb);
-        const UpTap ty = up_tap(sy, yc, h);
-        wy[it] = y <= yb ? (ty.i0 == iy ? ty.l0 : 0.f) + (ty.i1 == iy ? ty.l1 : 0.f) : 0.f;
-        const float *row = g + (size_t)yc * W;
-#pragma unroll
-        for (int t = 0; t < NW; ++t) v[it][t] = row[min(xa + t, W - 1)];
-    }
+    for (int t = 0; t < NT_; ++t) wxr[t] = s_wx[jj * NT_ + t];
     float acc = 0.f;
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        float rs = 0.f;
+    for (int it = 0; it < (NT_ + LPO - 1) / LPO; ++it) {
+        const int ty = l + it * LPO;
+        if (ty < NT_) {
+            const float *row = s_g + (R * ii + ty) * NC + c0;
+            float rs = 0.f;
 #pragma unroll
-        for (int t = 0; t < NW; ++t) rs = __builtin_fmaf(s_wx[oo * NW + t], v[it][t], rs);
-        acc = __builtin_fmaf(wy[it], rs, acc);
+            for (int t = 0; t < NT_; ++t) rs = __builtin_fmaf(wxr[t], row[t], rs);
+            acc = __builtin_fmaf(s_wy[ii * NT_ + ty], rs, acc);
+        }
     }
 #pragma unroll
     for (int m = 1; m < LPO; m <<= 1) acc += __shfl_xor(acc, m, 64);
-    if (l == 0 && oraw < n) gin[o] = acc;
+    const int jx = jx0 + jj, iy = iy0 + ii;
+    if (l == 0 && jx < w && iy < h) gin[((size_t)bc * h + iy) * w + jx] = acc;
 }
 
-// lanes per low-resolution pixel and footprint width by ratio (2*ratio + 3 columns); wider: the per-scale kernels
-static int finish_lpo(int W, int w)
-{
-    const int foot = (int)ceilf(2.0f * (float)W / (float)w) + 3;
-    return foot <= 8 ? 4 : (foot <= 12 ? 8 : (foot <= 20 ? 16 : 0));
-}
+// tile shape by ratio (host and device agree through these)
+static int finish_tw(int r) { return r == 2 ? 64 : (r == 4 ? 32 : 16); }
+static int finish_th(int r) { return 4; }
 
 __global__ __launch_bounds__(NT) void train_finish_kernel(FinishArgs a)
 {
-    __shared__ float s_wx[512];   // NOUT * NW: 64*8, 32*12, 16*20
+    __shared__ __attribute__((aligned(16))) float s_lds[FIN_LDS_FLOATS];
     const int blk = blockIdx.x;
     if (blk < a.up_first[MDX_MAX_SCALES]) {
         const int sc = blk >= a.up_first[3] ? 3 : (blk >= a.up_first[2] ? 2 : (blk >= a.up_first[1] ? 1 : 0));
         const float *gup = pick(a.gup, sc);
         float *gin = pick(a.gin, sc);
-        const int h = pick(a.h, sc), w = pick(a.w, sc);
-        const unsigned rel = (unsigned)(blk - pick4(a.up_first, sc));
-        const int foot = (int)ceilf(2.0f * (float)a.W / (float)w) + 3;
-        if (foot <= 8) upsample_bwd_body<8, 4>(gup, a.B, a.H, a.W, gin, h, w, rel, s_wx);
-        else if (foot <= 12) upsample_bwd_body<12, 8>(gup, a.B, a.H, a.W, gin, h, w, rel, s_wx);
-        else upsample_bwd_body<20, 16>(gup, a.B, a.H, a.W, gin, h, w, rel, s_wx);
+        const int h = pick(a.h, sc), w = pick(a.w, sc), r = pick(a.ratio, sc);
+        const int tx_n = pick(a.tiles_x, sc), ty_n = pick(a.tiles_y, sc);
+        const int rel = blk - pick4(a.up_first, sc);
+        const int tile_x = rel % tx_n, tile_y = (rel / tx_n) % ty_n, bc = rel / (tx_n * ty_n);
+        if (r == 2) upsample_bwd_tile<2, 64, 4, 1>(gup, a.H, a.W, gin, h, w, bc, tile_x, tile_y, s_lds);
+        else if (r == 4) upsample_bwd_tile<4, 32, 4, 2>(gup, a.H, a.W, gin, h, w, bc, tile_x, tile_y, s_lds);
+        else upsample_bwd_tile<8, 16, 4, 4>(gup, a.H, a.W, gin, h, w, bc, tile_x, tile_y, s_lds);
         return;
     }
     // reductions.  Loads are issued in groups of four independent ones (a dependent load -> add chain would pay one
     // memory round trip per element); the order of the additions is fixed.
-    __shared__ double s_red[NT / 64];
+    double *s_red = reinterpret_cast<double *>(s_lds);
     const int rblk = blk - a.up_first[MDX_MAX_SCALES];
     const int lane = threadIdx.x & 63;
     const int ngp = a.nscales * a.S * a.B * 12;
@@ -896,16 +921,20 @@ MDX_EXPORT int mdx_photometric_train(const mdx_train_desc *d, const float *const
     bool separate[MDX_MAX_SCALES] = {false, false, false, false};
     for (int s = 0; s < MDX_MAX_SCALES; ++s) {
         fa.up_first[s] = nblk;
-        fa.gup[s] = a.gup[s < d->nscales ? s : 0]; fa.gin[s] = gdisp[s < d->nscales ? s : 0];
-        fa.h[s] = d->h[s < d->nscales ? s : 0]; fa.w[s] = d->w[s < d->nscales ? s : 0];
+        const int ss = s < d->nscales ? s : 0;
+        fa.gup[s] = a.gup[ss]; fa.gin[s] = gdisp[ss]; fa.h[s] = d->h[ss]; fa.w[s] = d->w[ss];
+        fa.ratio[s] = 2; fa.tiles_x[s] = fa.tiles_y[s] = 1;
         if (s >= d->nscales || (d->h[s] == d->H && d->w[s] == d->W)) continue;
 #ifdef MDX_TRAIN_STAMPS
         if (const char *e = getenv("MDX_FINISH_SKIP")) if (strchr(e, '0' + s)) continue;   // diagnostic: leave a scale out
 #endif
-        const int lpo = finish_lpo(d->W, d->w[s]);
-        // the merged pass assumes one ratio for both axes and a footprint of at most 20 columns
-        if (lpo == 0 || (long long)d->H * d->w[s] != (long long)d->W * d->h[s]) { separate[s] = true; continue; }
-        nblk += (int)(((size_t)d->B * d->h[s] * d->w[s] * lpo + NT - 1) / NT);
+        // the tiled pass takes the integer ratios 2, 4, 8 (same on both axes); anything else the per-scale kernels
+        const int r = d->W / d->w[s];
+        if (d->W != r * d->w[s] || d->H != r * d->h[s] || (r != 2 && r != 4 && r != 8)) { separate[s] = true; continue; }
+        fa.ratio[s] = r;
+        fa.tiles_x[s] = (d->w[s] + finish_tw(r) - 1) / finish_tw(r);
+        fa.tiles_y[s] = (d->h[s] + finish_th(r) - 1) / finish_th(r);
+        nblk += fa.tiles_x[s] * fa.tiles_y[s] * d->B;
     }
     fa.up_first[MDX_MAX_SCALES] = nblk;
     const int ngp_blocks = (d->nscales * d->S * d->B * 12 + NT / 64 - 1) / (NT / 64);

@@ -14,7 +14,7 @@ def main():
     for d in dirs:
         for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
-                if "mdx::photometric" in r["Kernel_Name"]:
+                if "mdx::photometric" in r["Kernel_Name"] or "mdx::train_finish" in r["Kernel_Name"]:
                     agg[r["Kernel_Name"].replace("void ", "")[:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     lines = ["# rocprofv3 --pmc, mean per launch (tools/kbench.py: B=12, 192x640, S=2, all four scales)"]
     for k in sorted(agg):
