@@ -170,7 +170,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S <= 2 ? 3 :
     __shared__ float4 s_stash[3][2 * S][64];
 
     const int lane = threadIdx.x;
-    // ---- work item: level-major order (see TrainArgs), dispatched in block order ----
+    // ---- work item: level-major order (see TrainArgs), dispatched in block order.  Consecutive items (neighbouring
+    //      strips) go to different XCDs; an XCD-contiguous order inside each level was measured and is WORSE here
+    //      (fabric-side fetch 1.36 GB instead of 1.0 GB per launch, 349 us instead of 320 us on tools/kbench.py's data:
+    //      a contiguous run holds items of equal cost, and the XCDs drift apart) ----
     const int item_d = (int)blockIdx.x;
     const int lev = item_d >= a.lev_item0[2] ? 2 : (item_d >= a.lev_item0[1] ? 1 : 0);
     const int lev_first = lev == 2 ? a.lev_item0[2] : (lev == 1 ? a.lev_item0[1] : a.lev_item0[0]);
