@@ -232,6 +232,8 @@ def trainer_loop(args, frame_ids, steps, warmup, workers):
     opt.uint8_loader = not args.float_loader     # colours uint8 through the host pipeline, x/255 on the GPU
     opt.collate_step_keys = not args.float_loader
     opt.max_steps, opt.miopen_find = 0, args.miopen_find
+    if os.environ.get("MDX_SWITCH_INTERVAL"):
+        sys.setswitchinterval(float(os.environ["MDX_SWITCH_INTERVAL"]))
     tr = trainer(opt)
     tr.setting.set_train()
     log = {k: [] for k in tr.control.metric_name}

@@ -14,14 +14,13 @@ namespace mdx {
 
 constexpr int MEAN_CHUNK = NT * 4;   // pixels per block of the partial-mean pass
 
-// pass 1: per-block partial sums of disp (double), grid (nchunk, B)
-__global__ __launch_bounds__(NT) void smooth_partial_sum_kernel(const float *__restrict__ disp, int hw,
-                                                                double *__restrict__ psum)
+// pass 1: per-block partial sums of disp (double); block (bx of nbx, image by)
+MDX_DEV void partial_sum_body(const float *__restrict__ disp, int hw, double *__restrict__ psum, int bx, int nbx, int by)
 {
     __shared__ double s_red[NT / 64];
-    const float *d = disp + (size_t)blockIdx.y * hw;
+    const float *d = disp + (size_t)by * hw;
     double acc = 0.0;
-    const int base = blockIdx.x * MEAN_CHUNK;
+    const int base = bx * MEAN_CHUNK;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int i = base + k * NT + threadIdx.x;
@@ -33,8 +32,14 @@ __global__ __launch_bounds__(NT) void smooth_partial_sum_kernel(const float *__r
     if (threadIdx.x == 0) {
         double t = 0.0;
         for (int k = 0; k < NT / 64; ++k) t += s_red[k];
-        psum[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = t;
+        psum[(size_t)by * nbx + bx] = t;
     }
+}
+
+__global__ __launch_bounds__(NT) void smooth_partial_sum_kernel(const float *__restrict__ disp, int hw,
+                                                                double *__restrict__ psum)
+{
+    partial_sum_body(disp, hw, psum, blockIdx.x, gridDim.x, blockIdx.y);
 }
 
 // every block of the main pass re-reduces the (few) partial sums of its image: den = mean + 1e-7
@@ -63,24 +68,21 @@ MDX_DEV float edge_weight(const float *__restrict__ c0, size_t hw, size_t i, siz
 }
 
 // partials layout per block: [0] sum_x, [1] sum_y, [2] dot(G, disp)   (block -> one image row band)
-__global__ __launch_bounds__(NT) void smooth_main_kernel(const float *__restrict__ disp,
-                                                         const float *__restrict__ color,
-                                                         const double *__restrict__ psum, int nchunk, int normalize,
-                                                         float *__restrict__ den, int B, int h, int w,
-                                                         float *__restrict__ G, double *__restrict__ part)
+MDX_DEV void main_body(const float *__restrict__ disp, const float *__restrict__ color, const double *__restrict__ psum,
+                       int nchunk, int normalize, float *__restrict__ den, int B, int h, int w, float *__restrict__ G,
+                       double *__restrict__ part, int bx, int nbx, int b)
 {
     __shared__ double s_red[3][NT / 64];
-    const int b = blockIdx.y;
     const size_t hw = (size_t)h * w;
     const float *d = disp + (size_t)b * hw;
     const float *c0 = color + (size_t)b * 3 * hw;
     const float m = block_den(psum + (size_t)b * nchunk, nchunk, (int)hw, normalize, &s_red[0][0]);
-    if (blockIdx.x == 0 && threadIdx.x == 0) den[b] = m;
+    if (bx == 0 && threadIdx.x == 0) den[b] = m;
     const double Nx = (double)B * h * (w - 1), Ny = (double)B * (h - 1) * w;
     double sx = 0.0, sy = 0.0, dot = 0.0;
-    const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+    const size_t i = (size_t)bx * NT + threadIdx.x;
     if (i < hw) {
-        const int y = (int)(i / w), x = (int)(i % w);
+        const int y = (int)((unsigned)i / (unsigned)w), x = (int)((unsigned)i % (unsigned)w);
         const float n0 = d[i] / m;
         float gacc = 0.f;
         if (x + 1 < w) {
@@ -116,14 +118,22 @@ __global__ __launch_bounds__(NT) void smooth_main_kernel(const float *__restrict
     if (threadIdx.x < 3) {
         double t = 0.0;
         for (int k = 0; k < NT / 64; ++k) t += s_red[threadIdx.x][k];
-        part[((size_t)b * gridDim.x + blockIdx.x) * 3 + threadIdx.x] = t;
+        part[((size_t)b * nbx + bx) * 3 + threadIdx.x] = t;
     }
 }
 
+__global__ __launch_bounds__(NT) void smooth_main_kernel(const float *__restrict__ disp,
+                                                         const float *__restrict__ color,
+                                                         const double *__restrict__ psum, int nchunk, int normalize,
+                                                         float *__restrict__ den, int B, int h, int w,
+                                                         float *__restrict__ G, double *__restrict__ part)
+{
+    main_body(disp, color, psum, nchunk, normalize, den, B, h, w, G, part, blockIdx.x, gridDim.x, blockIdx.y);
+}
+
 // one block: loss = sum_x/Nx + sum_y/Ny (parallel strided sums + LDS tree); per-image dot -> dots[b]
-__global__ __launch_bounds__(NT) void smooth_finish_kernel(const double *__restrict__ part, int B, int nblk,
-                                                           int h, int w, float *__restrict__ loss,
-                                                           double *__restrict__ dots)
+MDX_DEV void finish_body(const double *__restrict__ part, int B, int nblk, int h, int w, float *__restrict__ loss,
+                         double *__restrict__ dots)
 {
     __shared__ double s_x[NT / 64], s_y[NT / 64];
     double sx = 0.0, sy = 0.0;
@@ -146,6 +156,13 @@ __global__ __launch_bounds__(NT) void smooth_finish_kernel(const double *__restr
     }
 }
 
+__global__ __launch_bounds__(NT) void smooth_finish_kernel(const double *__restrict__ part, int B, int nblk,
+                                                           int h, int w, float *__restrict__ loss,
+                                                           double *__restrict__ dots)
+{
+    finish_body(part, B, nblk, h, w, loss, dots);
+}
+
 // gdisp = G/m - dot/(m^2 * h*w)      (in place over G)
 __global__ __launch_bounds__(NT) void smooth_grad_kernel(float *__restrict__ G, const float *__restrict__ den,
                                                          const double *__restrict__ dots, int hw, size_t n,
@@ -156,6 +173,64 @@ __global__ __launch_bounds__(NT) void smooth_grad_kernel(float *__restrict__ G, 
     const int b = (int)(i / hw);
     const double m = (double)den[b];
     G[i] = (float)((double)G[i] / m - dots[b] / (m * m * (double)hw));
+}
+
+// ---- all scales of a step in one launch per pass (mdx_smooth_loss_multi) ----
+struct SmoothJobs {
+    int nscales, B, normalize;
+    int h[MDX_MAX_SCALES], w[MDX_MAX_SCALES], nblk[MDX_MAX_SCALES], nchunk[MDX_MAX_SCALES];
+    int first_main[MDX_MAX_SCALES + 1], first_sum[MDX_MAX_SCALES + 1], first_grad[MDX_MAX_SCALES + 1];   // block ranges
+    const float *disp[MDX_MAX_SCALES], *color[MDX_MAX_SCALES];
+    float *gdisp[MDX_MAX_SCALES], *den[MDX_MAX_SCALES];
+    double *dots[MDX_MAX_SCALES], *part[MDX_MAX_SCALES], *psum[MDX_MAX_SCALES];
+    float *loss;
+};
+
+template <typename T> MDX_DEV T spick(const T (&v)[MDX_MAX_SCALES], int s)
+{
+    return s == 0 ? v[0] : (s == 1 ? v[1] : (s == 2 ? v[2] : v[3]));
+}
+MDX_DEV int job_scale(const int (&first)[MDX_MAX_SCALES + 1], int blk)
+{
+    return blk >= first[3] ? 3 : (blk >= first[2] ? 2 : (blk >= first[1] ? 1 : 0));
+}
+MDX_DEV int job_first(const int (&first)[MDX_MAX_SCALES + 1], int s)
+{
+    return s == 0 ? first[0] : (s == 1 ? first[1] : (s == 2 ? first[2] : first[3]));
+}
+
+__global__ __launch_bounds__(NT) void smooth_multi_sum_kernel(SmoothJobs j)
+{
+    const int s = job_scale(j.first_sum, blockIdx.x), rel = blockIdx.x - job_first(j.first_sum, s);
+    const int nc = spick(j.nchunk, s);
+    partial_sum_body(spick(j.disp, s), spick(j.h, s) * spick(j.w, s), spick(j.psum, s), rel % nc, nc, rel / nc);
+}
+
+__global__ __launch_bounds__(NT) void smooth_multi_main_kernel(SmoothJobs j)
+{
+    const int s = job_scale(j.first_main, blockIdx.x), rel = blockIdx.x - job_first(j.first_main, s);
+    const int nb = spick(j.nblk, s);
+    main_body(spick(j.disp, s), spick(j.color, s), spick(j.psum, s), spick(j.nchunk, s), j.normalize, spick(j.den, s), j.B,
+              spick(j.h, s), spick(j.w, s), spick(j.gdisp, s), spick(j.part, s), rel % nb, nb, rel / nb);
+}
+
+__global__ __launch_bounds__(NT) void smooth_multi_finish_kernel(SmoothJobs j)
+{
+    const int s = blockIdx.x;
+    finish_body(spick(j.part, s), j.B, spick(j.nblk, s), spick(j.h, s), spick(j.w, s), j.loss + s, spick(j.dots, s));
+}
+
+__global__ __launch_bounds__(NT) void smooth_multi_grad_kernel(SmoothJobs j)
+{
+    if (!j.normalize) return;
+    const int s = job_scale(j.first_grad, blockIdx.x), rel = blockIdx.x - job_first(j.first_grad, s);
+    const int hw = spick(j.h, s) * spick(j.w, s);
+    const unsigned i = (unsigned)rel * NT + threadIdx.x;
+    if (i >= (unsigned)j.B * (unsigned)hw) return;
+    float *G = spick(j.gdisp, s);
+    const int b = (int)(i / (unsigned)hw);
+    const double m = (double)spick(j.den, s)[b];
+    G[i] = (float)((double)G[i] / m - spick(j.dots, s)[b] / (m * m * (double)hw));
 }
 
 static size_t smooth_nblk(int h, int w) { return ((size_t)h * w + NT - 1) / NT; }
@@ -201,5 +276,59 @@ MDX_EXPORT int mdx_smooth_loss(int B, int h, int w, const float *disp, const flo
         hipLaunchKernelGGL(smooth_grad_kernel, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0, st, gdisp,
                            (const float *)den, (const double *)dots, hw, n, normalize);
     }
+    return check_launch();
+}
+
+MDX_EXPORT size_t mdx_smooth_multi_workspace_bytes(int nscales, int B, const int32_t *h, const int32_t *w)
+{
+    if (nscales < 1 || nscales > MDX_MAX_SCALES || !h || !w) return 0;
+    size_t tot = 0;
+    for (int s = 0; s < nscales; ++s) {
+        const size_t one = mdx_smooth_workspace_bytes(B, h[s], w[s]);
+        if (!one) return 0;
+        tot += (one + 15) & ~(size_t)15;
+    }
+    return tot;
+}
+
+MDX_EXPORT int mdx_smooth_loss_multi(int nscales, int B, const int32_t *h, const int32_t *w, const float *const *disp,
+                                     const float *const *color, int normalize, float *loss, float *const *gdisp,
+                                     void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!h || !w || !disp || !color || !loss) return MDX_ERR_NULL_POINTER;
+    if (nscales < 1 || nscales > MDX_MAX_SCALES || B <= 0) return MDX_ERR_BAD_SHAPE;
+    if (!workspace || workspace_bytes < mdx_smooth_multi_workspace_bytes(nscales, B, h, w)) return MDX_ERR_WORKSPACE;
+    if (!aligned(workspace, 8)) return MDX_ERR_MISALIGNED;
+    SmoothJobs j = {};
+    j.nscales = nscales; j.B = B; j.normalize = normalize; j.loss = loss;
+    char *ws = (char *)workspace;
+    int nm = 0, ns = 0, ng = 0;
+    bool grads = false;
+    for (int s = 0; s < MDX_MAX_SCALES; ++s) {
+        j.first_main[s] = nm; j.first_sum[s] = ns; j.first_grad[s] = ng;
+        const int ss = s < nscales ? s : 0;
+        if (!disp[ss] || !color[ss]) return MDX_ERR_NULL_POINTER;
+        if (h[ss] < 2 || w[ss] < 2 || (long long)B * h[ss] * w[ss] >= (1ll << 31)) return MDX_ERR_BAD_SHAPE;
+        j.h[s] = h[ss]; j.w[s] = w[ss]; j.disp[s] = disp[ss]; j.color[s] = color[ss];
+        j.gdisp[s] = gdisp ? gdisp[ss] : nullptr;
+        j.nblk[s] = (int)smooth_nblk(h[ss], w[ss]); j.nchunk[s] = (int)smooth_nchunk(h[ss], w[ss]);
+        if (s >= nscales) { j.den[s] = j.den[0]; j.dots[s] = j.dots[0]; j.part[s] = j.part[0]; j.psum[s] = j.psum[0]; continue; }
+        const size_t den_bytes = ((size_t)B * sizeof(float) + 7) & ~(size_t)7;
+        j.den[s] = (float *)ws;
+        j.dots[s] = (double *)(ws + den_bytes);
+        j.part[s] = j.dots[s] + B;
+        j.psum[s] = j.part[s] + (size_t)B * j.nblk[s] * 3;
+        ws += (mdx_smooth_workspace_bytes(B, h[s], w[s]) + 15) & ~(size_t)15;
+        nm += j.nblk[s] * B; ns += j.nchunk[s] * B;
+        ng += (int)(((size_t)B * h[s] * w[s] + NT - 1) / NT);
+        grads = grads || j.gdisp[s] != nullptr;
+        if ((j.gdisp[s] != nullptr) != (j.gdisp[0] != nullptr)) return MDX_ERR_NULL_POINTER;   // all or none
+    }
+    j.first_main[MDX_MAX_SCALES] = nm; j.first_sum[MDX_MAX_SCALES] = ns; j.first_grad[MDX_MAX_SCALES] = ng;
+    hipStream_t st = (hipStream_t)stream;
+    if (normalize) hipLaunchKernelGGL(smooth_multi_sum_kernel, dim3(ns), dim3(NT), 0, st, j);
+    hipLaunchKernelGGL(smooth_multi_main_kernel, dim3(nm), dim3(NT), 0, st, j);
+    hipLaunchKernelGGL(smooth_multi_finish_kernel, dim3(nscales), dim3(NT), 0, st, j);
+    if (grads && normalize) hipLaunchKernelGGL(smooth_multi_grad_kernel, dim3(ng), dim3(NT), 0, st, j);
     return check_launch();
 }

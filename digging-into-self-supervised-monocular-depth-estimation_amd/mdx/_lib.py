@@ -61,6 +61,7 @@ SYMBOLS = {
     "mdx_param2matrix_fwd": C.c_int, "mdx_param2matrix_bwd": C.c_int,
     "mdx_train_desc_init": C.c_int, "mdx_photometric_train_workspace_bytes": C.c_size_t,
     "mdx_photometric_train": C.c_int,
+    "mdx_smooth_multi_workspace_bytes": C.c_size_t, "mdx_smooth_loss_multi": C.c_int,
 }
 
 

@@ -287,6 +287,40 @@ def smooth_loss(disp, color, normalize=True):
     return _SmoothLoss.apply(disp, color, normalize)
 
 
+class _SmoothLossMulti(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, normalize, colors, *disps):
+        disps = [_f32c(d) for d in disps]
+        colors = [_f32c(c) for c in colors]
+        n = len(disps)
+        B = disps[0].shape[0]
+        dev = disps[0].device
+        hs = (C.c_int32 * n)(*[int(d.shape[2]) for d in disps])
+        ws_ = (C.c_int32 * n)(*[int(d.shape[3]) for d in disps])
+        loss = torch.empty(n, device=dev, dtype=torch.float32)
+        need = any(ctx.needs_input_grad[2:])
+        gs = [torch.empty_like(d) for d in disps] if need else None
+        nws = lib().mdx_smooth_multi_workspace_bytes(n, B, hs, ws_)
+        ws = _ws(nws, dev)
+        check(lib().mdx_smooth_loss_multi(n, B, hs, ws_, _lib.ptr_array(disps), _lib.ptr_array(colors), int(normalize),
+                                          ptr(loss), _lib.ptr_array(gs) if need else None, ptr(ws, torch.float64),
+                                          C.c_size_t(nws), stream()), "mdx_smooth_loss_multi")
+        if need:
+            ctx.save_for_backward(*gs)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        gs = ctx.saved_tensors
+        return (None, None) + tuple(g * gout[k] for k, g in enumerate(gs))
+
+
+def smooth_loss_multi(disps, colors, normalize=True):
+    """SmoothLoss()(disp_s, color_s) for every scale of a step -> tensor [nscales]; each of the four passes is ONE
+    launch for all scales (the per-scale op takes 16 launches per step)."""
+    return _SmoothLossMulti.apply(bool(normalize), list(colors), *disps)
+
+
 # ------------------------------------------------------------------------------------------------
 # fine-grained ops (reference API granularity)
 # ------------------------------------------------------------------------------------------------

@@ -16,11 +16,25 @@ class control(object):
         self.opt = opt
         self.device = device
         self.metric_name = ["loss", "abs_rel", "sq_rel", "rmse", "rmse_log", "a1", "a2", "a3"]
+        # the train-time depth monitor reads two tensors of the finished step and produces seven scalars nobody looks
+        # at before the epoch ends: it runs on a SIDE stream, beside the next step's convolutions
+        self._side = None
+        if str(device).startswith("cuda") and getattr(opt, "metric_side_stream", True):
+            self._side = torch.cuda.Stream(device)
 
     def metric(self, inputs, outputs, metric_dict):
         metric_dict["loss"].append(outputs["loss"].detach())
         if ("depth", 0) in inputs and ("depth", 0, 0) in outputs:
-            depth_errors = compute_depth_metric(inputs, outputs, "torch")
+            gt, depth = inputs[("depth", 0)], outputs[("depth", 0, 0)]
+            if self._side is not None and gt.is_cuda and depth.is_cuda:
+                main = torch.cuda.current_stream(gt.device)
+                self._side.wait_stream(main)
+                with torch.cuda.stream(self._side):
+                    depth_errors = compute_depth_metric(inputs, outputs, "torch")
+                for t in (gt, depth):
+                    t.record_stream(self._side)          # their memory must not be reused before the monitor has read it
+            else:
+                depth_errors = compute_depth_metric(inputs, outputs, "torch")
             for index, metric in enumerate(self.metric_name[1:]):
                 metric_dict[metric].append(depth_errors[index].detach())
         return metric_dict
@@ -30,6 +44,8 @@ class control(object):
         if not len(values):
             return float("nan")
         if torch.is_tensor(values[0]):
+            if values[0].is_cuda:
+                torch.cuda.synchronize(values[0].device)    # the monitor's side stream included
             return float(torch.stack([v.float().reshape(()) for v in values]).mean().cpu())
         return float(np.mean(values))
 

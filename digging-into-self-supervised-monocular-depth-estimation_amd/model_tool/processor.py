@@ -68,7 +68,7 @@ class compute(object):
             # uint8 colours (opt.uint8_loader): ToTensor's x / 255 happens here, on the device -- bit-identical
             if (torch.is_tensor(inputs[key]) and inputs[key].dtype == torch.uint8 and isinstance(key, tuple)
                     and key[0] in ("color", "color_aug") and inputs[key].device == dev):
-                inputs[key] = inputs[key].float().div_(255.0)
+                inputs[key] = torch.true_divide(inputs[key], 255.0)      # one kernel: float32(x) / 255, correctly rounded
         with self._autocast():
             if self.opt.pose_type == "shared":
                 all_frames = torch.cat([inputs[("color_aug", f, 0)] for f in self.opt.frame_ids])
@@ -224,6 +224,11 @@ class compute(object):
                                         need_depth=(opt.scales[0] == 0))
             if train["depth"] is not None:
                 outputs[("depth", 0, 0)] = train["depth"]
+        # fused mode: the smoothness term of every scale with each of its passes launched once (4 launches, not 16)
+        smooth_all = None
+        if self.fused and len(opt.scales) <= 4 and target.is_cuda:
+            smooth_all = F.smooth_loss_multi([outputs[("disp", s)].float() for s in opt.scales],
+                                             [inputs[("color", 0, s)] for s in opt.scales])
         for k, scale in enumerate(opt.scales):
             disp = outputs[("disp", scale)].float()
             color = inputs[("color", 0, scale)]
@@ -257,7 +262,7 @@ class compute(object):
                     to_optimise, idxs = torch.min(combined_loss, dim=1)
                     outputs[("automask", scale)] = idxs
                 mean_min = to_optimise.mean()
-            smooth_loss = setting.loss["edge_aware"](disp=disp, color=color)
+            smooth_loss = smooth_all[k] if smooth_all is not None else setting.loss["edge_aware"](disp=disp, color=color)
             scale_loss = mean_min + opt.disp_smoothness * smooth_loss / (2 ** scale)
             total_loss = total_loss + scale_loss
         total_loss = total_loss / len(opt.scales)

@@ -180,6 +180,13 @@ size_t mdx_smooth_workspace_bytes(int B, int h, int w);
 int mdx_smooth_loss(int B, int h, int w, const float *disp, const float *color, int normalize, float *loss,
                     float *gdisp, void *workspace, size_t workspace_bytes, void *stream);
 
+/* The same for every scale of a step, each pass launched once for all scales (the scale loop of processor.py:208):
+ * h, w, disp, color, gdisp: HOST arrays of nscales entries (gdisp NULL or all entries given); loss [nscales]. */
+size_t mdx_smooth_multi_workspace_bytes(int nscales, int B, const int32_t *h, const int32_t *w);
+int mdx_smooth_loss_multi(int nscales, int B, const int32_t *h, const int32_t *w, const float *const *disp,
+                          const float *const *color, int normalize, float *loss, float *const *gdisp,
+                          void *workspace, size_t workspace_bytes, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Fine-grained ops behind the reference's model_layer / model_loss API (each differentiable)
  * ---------------------------------------------------------------------------------------- */

@@ -161,3 +161,24 @@ def test_train_kernel_matches_per_scale_kernels(G):
     for s in range(4):
         G.assert_close(d1[s].grad, d2[s].grad.cpu().numpy(), "grad disp s%d" % s, rel=1e-4)
     G.assert_close(P1.grad, P2.grad.cpu().numpy(), "grad P", rel=1e-4)
+
+
+def test_smooth_loss_multi_vs_per_scale_and_golden(G):
+    """mdx_smooth_loss_multi (every scale, each pass launched once) against the per-scale op and the reference's values."""
+    for name in ("mono_24x40_b2", "multi_64x160_b2"):
+        c = goldens.Case(name)
+        d1 = [G.t(c["disp_s%d" % s]).requires_grad_(True) for s in range(c.n_scales)]
+        d2 = [G.t(c["disp_s%d" % s]).requires_grad_(True) for s in range(c.n_scales)]
+        cols = [G.t(c.color(0, s)) for s in range(c.n_scales)]
+        multi = G.F.smooth_loss_multi(d1, cols)
+        wts = torch.tensor([1.0 / (2 ** s) for s in range(c.n_scales)], device=G.DEV)
+        (multi * wts).sum().backward()
+        tot = 0
+        for s in range(c.n_scales):
+            one = G.F.smooth_loss(d2[s], cols[s])
+            G.assert_close(multi[s], c["smooth_s%d" % s], "smooth s%d vs reference" % s)
+            G.assert_close(multi[s], one.detach().cpu().numpy(), "smooth s%d vs per-scale op" % s, rel=1e-6)
+            tot = tot + one * wts[s]
+        tot.backward()
+        for s in range(c.n_scales):
+            G.assert_close(d1[s].grad, d2[s].grad.cpu().numpy(), "smooth grad s%d" % s, rel=1e-6)

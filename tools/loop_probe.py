@@ -48,3 +48,23 @@ def full():
     bb = next(pit)
     tr.control.metric(bb, tr.train_step(bb), log)
 timed("full loop", full)
+
+# host-side cost of enqueueing one step (no synchronisation inside the loop): is the loop close to launch-bound?
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(10):
+    tr.train_step(dev)
+t_host = (time.perf_counter() - t0) / 10
+torch.cuda.synchronize()
+print("%-46s %7.2f ms/step" % ("host enqueue time of train_step (resident)", 1e3 * t_host), flush=True)
+t0 = time.perf_counter()
+for _ in range(10):
+    tr.control.metric(dev, out, log)
+t_m = (time.perf_counter() - t0) / 10
+torch.cuda.synchronize()
+print("%-46s %7.2f ms/step" % ("host enqueue time of control.metric", 1e3 * t_m), flush=True)
+t0 = time.perf_counter()
+for _ in range(10):
+    bb = next(pit)
+t_n = (time.perf_counter() - t0) / 10
+print("%-46s %7.2f ms/step" % ("host time of next(prefetcher) [queue + uploads]", 1e3 * t_n), flush=True)
