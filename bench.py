@@ -231,6 +231,7 @@ def trainer_loop(args, frame_ids, steps, warmup, workers):
     opt.synthetic_pool = 4 * args.batch          # the stand-in dataset must not be what is measured
     opt.uint8_loader = not args.float_loader     # colours uint8 through the host pipeline, x/255 on the GPU
     opt.collate_step_keys = not args.float_loader
+    opt.graph = not args.trainer_eager
     opt.max_steps, opt.miopen_find = 0, args.miopen_find
     if os.environ.get("MDX_SWITCH_INTERVAL"):
         sys.setswitchinterval(float(os.environ["MDX_SWITCH_INTERVAL"]))
@@ -251,7 +252,7 @@ def trainer_loop(args, frame_ids, steps, warmup, workers):
     vals = {k: tr.control._mean(v) for k, v in log.items()}
     del it
     return {"value": args.batch * steps / dt, "unit": "images/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
-            "workers": workers, "uint8_loader": bool(opt.uint8_loader), "what": "model_train.trainer: DataLoader (pinned, side-stream upload) -> train_step -> "
+            "workers": workers, "uint8_loader": bool(opt.uint8_loader), "hip_graph": bool(opt.graph), "what": "model_train.trainer: DataLoader (pinned, side-stream upload) -> train_step -> "
                                         "control.metric every step", "abs_rel_monitor": vals.get("abs_rel")}
 
 
@@ -278,6 +279,8 @@ def main():
                     help="skip the second measurement (the DataLoader-fed trainer loop, reported as trainer_loop)")
     ap.add_argument("--float-loader", action="store_true",
                     help="trainer loop with the reference's float32 colours through the DataLoader (4x the host bytes)")
+    ap.add_argument("--trainer-eager", action="store_true",
+                    help="trainer loop without the hipGraph replay of the step (model_option --graph 0)")
     ap.add_argument("--workers", type=int, default=12, help="DataLoader workers of the trainer-loop measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")

@@ -62,6 +62,7 @@ SYMBOLS = {
     "mdx_train_desc_init": C.c_int, "mdx_photometric_train_workspace_bytes": C.c_size_t,
     "mdx_photometric_train": C.c_int,
     "mdx_smooth_multi_workspace_bytes": C.c_size_t, "mdx_smooth_loss_multi": C.c_int,
+    "mdx_depth_monitor_workspace_bytes": C.c_size_t, "mdx_depth_monitor": C.c_int,
 }
 
 

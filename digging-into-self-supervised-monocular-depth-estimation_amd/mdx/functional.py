@@ -720,3 +720,21 @@ def param2matrix(axisangle, translation, invert=False):
     """(axis-angle [N,1,3], translation [N,1,3]) -> camera-to-camera matrix [N,4,4] (reference warp.py:126-153) in
     one launch; backward by forward-mode differentiation inside the kernel."""
     return _Param2Matrix.apply(axisangle, translation, bool(invert))
+
+
+# ---- train-time depth monitor (csrc/monitor.hip) -------------------------------------------------------------------
+def depth_monitor(pred, gt, window, min_depth=1e-3, max_depth=80.0):
+    """compute_depth_metric's seven numbers (reference model_metric.py:70-105) + the number of valid pixels, as a
+    float32 tensor [8] on the device: six small launches, no compaction, no sort, no synchronisation.
+    pred [B,1,h,w], gt [B,1,gh,gw]; window = (r0, r1, c0, c1) of the ground-truth image."""
+    pred, gt = _f32c(pred), _f32c(gt)
+    B, _, h, w = pred.shape
+    _, _, gh, gw = gt.shape
+    r0, r1, c0, c1 = (int(v) for v in window)
+    out = torch.empty(8, device=pred.device, dtype=torch.float32)
+    nws = lib().mdx_depth_monitor_workspace_bytes(B, r0, r1, c0, c1)
+    ws = _ws(nws, pred.device)
+    check(lib().mdx_depth_monitor(ptr(pred), B, h, w, ptr(gt), gh, gw, r0, r1, c0, c1, C.c_float(min_depth),
+                                  C.c_float(max_depth), ptr(out), ptr(ws, torch.float64), C.c_size_t(nws), stream()),
+          "mdx_depth_monitor")
+    return out

@@ -74,9 +74,15 @@ def compute_depth_metric(inputs, outputs, lib="torch"):
     gt = inputs[("depth", 0)]
     gh, gw = gt.shape[-2:]
     pred = outputs[("depth", 0, 0)].detach()
-    pred = torch.clamp(TF.interpolate(pred, [gh, gw], mode="bilinear", align_corners=False), 1e-3, 80)
     r0, r1 = int(0.40810811 * gh), int(0.99189189 * gh)
     c0, c1 = int(0.03594771 * gw), int(0.96405229 * gw)
+    if lib == "torch" and gt.is_cuda and pred.is_cuda and gt.dtype == torch.float32 and pred.dtype == torch.float32:
+        # GPU: the hand-written monitor (csrc/monitor.hip): exact medians by radix selection, six small launches
+        # (the torch-op form below costs ~100 kernels and two sorts: 2.0 ms against ~0.05 ms per step at batch 12)
+        from mdx import functional as F
+        out = F.depth_monitor(pred, gt, (r0, r1, c0, c1), 1e-3, 80.0)
+        return tuple(out[k] for k in range(7))
+    pred = torch.clamp(TF.interpolate(pred, [gh, gw], mode="bilinear", align_corners=False), 1e-3, 80)
     if not hasattr(torch, "nonzero_static"):
         mask = gt > 0
         crop = torch.zeros_like(mask)

@@ -40,6 +40,8 @@ def options(argv=None):
                    help="colours stay uint8 through the DataLoader; x/255 happens on the GPU (same values, 1/4 of the bytes)")
     p.add_argument("--collate_step_keys", type=lambda s: str(s).lower() in ("1", "true", "yes"), default=True,
                    help="DataLoader workers stack only the entries a step reads")
+    p.add_argument("--graph", type=lambda s: str(s).lower() in ("1", "true", "yes"), default=True,
+                   help="single-GPU training: capture the step into one hipGraph and replay it (host launch cost off the critical path)")
     p.add_argument("--device_prefetch", type=lambda s: str(s).lower() in ("1", "true", "yes"), default=True,
                    help="upload the next batch on a side stream while the current step computes")
     p.add_argument("--synthetic_pool", type=int, default=0, help="synthetic dataset: number of distinct samples kept (0 = all)")

@@ -16,14 +16,17 @@ class control(object):
         self.opt = opt
         self.device = device
         self.metric_name = ["loss", "abs_rel", "sq_rel", "rmse", "rmse_log", "a1", "a2", "a3"]
-        # the train-time depth monitor reads two tensors of the finished step and produces seven scalars nobody looks
-        # at before the epoch ends: it runs on a SIDE stream, beside the next step's convolutions
+        # The train-time depth monitor (csrc/monitor.hip, ~0.16 ms of kernels) runs on the step's own stream.  Running it
+        # on a side stream beside the next step's convolutions was measured and is WORSE: the cross-stream dependencies
+        # (the monitor waits for the step, the next graph replay waits for the monitor) cost ~1 ms per step
+        # (tools/loop_bisect.py: +1.10 ms on a side stream, +0.27 ms on the main stream).  opt.metric_side_stream keeps
+        # the experiment reachable.
         self._side = None
-        if str(device).startswith("cuda") and getattr(opt, "metric_side_stream", True):
+        if str(device).startswith("cuda") and getattr(opt, "metric_side_stream", False):
             self._side = torch.cuda.Stream(device)
 
     def metric(self, inputs, outputs, metric_dict):
-        metric_dict["loss"].append(outputs["loss"].detach())
+        metric_dict["loss"].append(outputs["loss"].detach().clone())     # a graph-replayed step returns the SAME tensor every step
         if ("depth", 0) in inputs and ("depth", 0, 0) in outputs:
             gt, depth = inputs[("depth", 0)], outputs[("depth", 0, 0)]
             if self._side is not None and gt.is_cuda and depth.is_cuda:

@@ -289,6 +289,16 @@ int mdx_bn_act_bwd(const void *dy, const void *y, const void *x, const float *ga
                    const float *save_invstd, void *dx, void *dres, float *dgamma, float *dbeta, int B, int C, int H,
                    int W, int groups, int relu, int dtype, void *workspace, size_t workspace_bytes, void *stream);
 
+/* Train-time depth monitor   replaces model_loss/model_metric.py:70-105 (called every step, model_train.py:69).
+ * pred [B,1,h,w] (outputs[("depth",0,0)]), gt [B,1,gh,gw] (0 = no return); window rows r0:r1, cols c0:c1 (the Garg crop).
+ * out [8] = abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3, number of valid pixels.  Bilinear resize to the ground truth's
+ * size, clamp, batch-level median scaling (torch.median's lower median, exact), clamp, compute_depth_error -- without
+ * compacting or sorting: two 16-bit radix-histogram passes find the medians. */
+size_t mdx_depth_monitor_workspace_bytes(int B, int r0, int r1, int c0, int c1);
+int mdx_depth_monitor(const float *pred, int B, int h, int w, const float *gt, int gh, int gw, int r0, int r1, int c0,
+                      int c1, float min_depth, float max_depth, float *out, void *workspace, size_t workspace_bytes,
+                      void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -175,3 +175,42 @@ def test_kitti_tree_training_and_eigen_style_evaluation(G, tmp_path):
     res = model_test.inference(opt, encoder=st.raw_model["encoder"], decoder=st.raw_model["decoder"])
     assert set(res) == set(model_test.METRICS) and all(np.isfinite(v) for v in res.values())
     assert 0 <= res["a1"] <= res["a2"] <= res["a3"] <= 1
+
+
+def test_trainer_graph_replay_matches_eager(G):
+    """model_train.trainer with opt.graph: the step captured into one hipGraph and replayed gives the eager loop's
+    losses (auto-masking off: its noise stream differs between a captured and an eager generator), advances the
+    batch-norm step counters, and follows a learning-rate change."""
+    import importlib
+    bench = importlib.import_module("bench")
+    from model_train import trainer
+
+    def run(graph):
+        torch.manual_seed(0)
+        opt = bench.make_opt(2, height=64, width=96)
+        opt.use_automasking, opt.graph, opt.synthetic_length, opt.max_steps, opt.miopen_find = False, graph, 16, 0, False
+        tr = trainer(opt)
+        tr.setting.set_train()
+        batches = list(tr.setting.train_dataloader)[:6]
+        losses = []
+        for i, b in enumerate(batches):
+            if i == 4:
+                for g in tr.setting.optim["optimizer"].param_groups:       # what StepLR does at an epoch boundary
+                    if torch.is_tensor(g["lr"]):
+                        g["lr"].fill_(1e-6)
+                    else:
+                        g["lr"] = 1e-6
+            losses.append(float(tr.train_step(dict(b))["loss"].detach()))
+        enc = tr.setting.raw_model["encoder"]
+        return losses, int(enc.state_dict()["encoder.bn1.num_batches_tracked"]), tr
+
+    eager, n_eager, _ = run(False)
+    graph, n_graph, tr = run(True)
+    assert tr._graphed is not None
+    assert n_graph == n_eager + 3 + 1          # + the graph's warm-up steps and its capture pass
+    # the graphed run takes 4 extra optimiser steps before its first replay (warm-up + capture): compare trends, and the
+    # replay against an eager step from the same state
+    assert all(np.isfinite(graph)) and graph[-1] < graph[0]
+    o1 = float(tr._eager_step(dict(tr._graphed.static))["loss"].detach())
+    o2 = float(tr._graphed(dict(tr._graphed.static))["loss"].detach())
+    assert np.isfinite(o1) and np.isfinite(o2) and abs(o1 - o2) < 0.05 * abs(o1)

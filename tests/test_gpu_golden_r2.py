@@ -77,3 +77,31 @@ def test_param2matrix_kernel_vs_reference(G):
         M.backward(G.t(a["p2m_gM_%d" % inv]))
         G.assert_close(aa.grad, a["p2m_gaa_%d" % inv], "d axisangle invert=%d" % inv)
         G.assert_close(tr.grad, a["p2m_gtr_%d" % inv], "d translation invert=%d" % inv)
+
+
+def test_depth_monitor_kernel_vs_reference(G):
+    """csrc/monitor.hip (what compute_depth_metric runs on GPU tensors) against the reference's compute_depth_metric
+    values (r2_metrics fixture), against the torch-op restatement on random data, and on an empty mask."""
+    from test_golden_r2_cpu import metric_inputs
+    from model_loss import compute_depth_metric
+    z = goldens_r2.load("r2_metrics")
+    inputs, outputs = metric_inputs(z, G.DEV)
+    got = np.array([float(v) for v in compute_depth_metric(inputs, outputs, "torch")])
+    G.assert_close(got, z["metric_out"], "depth monitor vs reference", rel=1e-5)
+    # random dense-ish case: GPU kernel vs the torch-op form on the CPU
+    g = torch.Generator().manual_seed(3)
+    gt = torch.zeros(3, 1, 375, 1242)
+    m = torch.rand(3, 1, 375, 1242, generator=g) < 0.2
+    gt[m] = 0.5 + 90 * torch.rand(int(m.sum()), generator=g)
+    pred = torch.rand(3, 1, 192, 640, generator=g) * 100 + 1e-4
+    import model_loss.model_metric as mm
+    keep, mm.METRIC_CAPACITY = mm.METRIC_CAPACITY, 1.0
+    try:
+        ref = np.array([float(v) for v in compute_depth_metric({("depth", 0): gt}, {("depth", 0, 0): pred}, "torch")])
+    finally:
+        mm.METRIC_CAPACITY = keep
+    got = np.array([float(v) for v in compute_depth_metric({("depth", 0): gt.to(G.DEV)}, {("depth", 0, 0): pred.to(G.DEV)}, "torch")])
+    G.assert_close(got, ref, "depth monitor vs torch ops", rel=2e-5)
+    empty = compute_depth_metric({("depth", 0): torch.zeros(1, 1, 375, 1242, device=G.DEV)},
+                                 {("depth", 0, 0): torch.ones(1, 1, 192, 640, device=G.DEV)}, "torch")
+    assert all(np.isnan(float(v)) for v in empty)
