@@ -23,10 +23,12 @@ if [ "$1" = "--collect" ]; then
     exit 0
 fi
 mkdir -p "$OUT" && cd /tmp && export TMPDIR=/tmp
-python3 "$ROOT/bench.py" > "$OUT/bench_full.json" 2> "$OUT/bench_full.err" || exit 1
-python3 "$ROOT/bench.py" --no-cpu-baseline --no-trainer-loop --per-scale-kernels > "$OUT/bench_per_scale.json" 2> "$OUT/bench_per_scale.err" || exit 1
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_stats" -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-trainer-loop > "$OUT/bench_stats.log" 2>&1 || exit 1
+# counters first: bench.py quotes them (for this very build of the library) next to the HBM fraction
 python3 "$ROOT/tools/kbench.py" --what fwd,bwd,ident,train --reps 20 > "$OUT/kbench.txt" 2>&1 || exit 1
 bash "$ROOT/tools/pmc_train.sh" > "$OUT/pmc_train.log" 2>&1 || exit 1
 python3 "$ROOT/tools/pmc_to_json.py" "$ROOT/gpurun_out/pmc_train" "$OUT/train_kernel_pmc.json" 12 192 640 2 4 > "$OUT/pmc_json.log" 2>&1 || exit 1
+cp "$OUT/train_kernel_pmc.json" "$ROOT/profiles/r02_train_kernel_pmc.json"
+python3 "$ROOT/bench.py" > "$OUT/bench_full.json" 2> "$OUT/bench_full.err" || exit 1
+python3 "$ROOT/bench.py" --no-cpu-baseline --no-trainer-loop --per-scale-kernels > "$OUT/bench_per_scale.json" 2> "$OUT/bench_per_scale.err" || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_stats" -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-trainer-loop > "$OUT/bench_stats.log" 2>&1 || exit 1
 tail -c 600 "$OUT/bench_full.json"
