@@ -191,13 +191,15 @@ class _PhotometricTrain(torch.autograd.Function):
     depth0 or None, to_opt_0.. or None); keeps only the unit-upstream gradients for backward."""
 
     @staticmethod
-    def forward(ctx, P, target, invK, ident, cfg, noises, sources, *disps):
+    def forward(ctx, target, invK, ident, cfg, noises, sources, nP, *tensors):
+        # tensors = nP projection tensors (1: shared by the scales; nscales: one per scale) followed by the disparities
+        Pl, disps = tensors[:nP], tensors[nP:]
         nsc = len(disps)
         disps = [_f32c(x) for x in disps]
         target, invK = _f32c(target), _f32c(invK)
         sources = [_f32c(x) for x in sources]
-        per_scale_P = isinstance(P, (list, tuple))
-        Ps = [_f32c(x) for x in P] if per_scale_P else [_f32c(P)] * nsc
+        per_scale_P = nP > 1
+        Ps = [_f32c(x) for x in Pl] if per_scale_P else [_f32c(Pl[0])] * nsc
         B, _, H, W = target.shape
         S = len(sources)
         automask = cfg["automask"]
@@ -235,24 +237,26 @@ class _PhotometricTrain(torch.autograd.Function):
         gP, *gdisp = ctx.saved_tensors
         g = g_sums.float()
         gPs = gP * g.view(-1, 1, 1, 1, 1)
-        gP_out = [gPs[s] for s in range(gP.shape[0])] if ctx.per_scale_P else gPs.sum(0)
-        return (gP_out, None, None, None, None, None, None) + tuple(gd * g[s] for s, gd in enumerate(gdisp))
+        gP_out = tuple(gPs[s] for s in range(gP.shape[0])) if ctx.per_scale_P else (gPs.sum(0),)
+        return (None, None, None, None, None, None, None) + gP_out + tuple(gd * g[s] for s, gd in enumerate(gdisp))
 
 
 def photometric_train(disps, P, target, sources, invK, ident=None, noises=None, automask=True, min_depth=0.1,
                       max_depth=100.0, need_depth=False, need_to_opt=False, rows_per_chunk=0):
     """The training step's photometric term for every scale at once: forward and gradient in one launch.
 
-    disps: list of [B,1,h_s,w_s] (grad); P [S,B,3,4] (grad; shared by the scales);
+    disps: list of [B,1,h_s,w_s] (grad); P [S,B,3,4] (grad) shared by the scales, or a list with one P per scale
+    (posecnn: the translation is scaled by the scale's mean inverse depth, processor.py:153-157);
     noises: list of [B,S,H,W] (automask).  Returns dict: 'sums' [nscales] (differentiable: sum over pixels of
     to_optimise per scale), 'idx' (list of uint8 [B,H,W]), 'depth' (scale 0, optional), 'to_opt' (optional list)."""
-    if isinstance(P, (list, tuple)):
-        raise _lib.MdxError("photometric_train: scale-dependent projections (posecnn) take the per-scale path")
+    Pl = list(P) if isinstance(P, (list, tuple)) else [P]
+    if len(Pl) not in (1, len(disps)):
+        raise _lib.MdxError("photometric_train: %d projections for %d scales (one, or one per scale)" % (len(Pl), len(disps)))
     cfg = dict(automask=bool(automask), min_depth=float(min_depth), max_depth=float(max_depth),
                need_depth=bool(need_depth), need_to_opt=bool(need_to_opt), rows_per_chunk=int(rows_per_chunk))
     n = len(disps)
-    out = _PhotometricTrain.apply(P, target, invK, ident, cfg, list(noises) if noises is not None else None,
-                                  list(sources), *disps)
+    out = _PhotometricTrain.apply(target, invK, ident, cfg, list(noises) if noises is not None else None,
+                                  list(sources), len(Pl), *Pl, *disps)
     res = dict(sums=out[0], idx=list(out[1:1 + n]), depth=out[1 + n])
     res["to_opt"] = list(out[2 + n:2 + 2 * n]) if need_to_opt else None
     return res

@@ -206,10 +206,9 @@ class compute(object):
         ident = None
         if self.fused and automask:
             ident = F.identity_loss(target, sources)          # once per step (scale-independent)
-        # training: every scale's photometric term and its gradient in one launch.  The projection must not depend on
-        # the scale (posecnn scales the translation by the scale's depth: per-scale path).
+        # training: every scale's photometric term and its gradient in one launch (posecnn: one projection per scale)
         train = None
-        if (self.fused and self.fused_train and torch.is_grad_enabled() and opt.pose_type != "posecnn"
+        if (self.fused and self.fused_train and torch.is_grad_enabled()
                 and len(opt.scales) <= 4 and any(outputs[("disp", s)].requires_grad for s in opt.scales)):
             nsc = len(opt.scales)
             noises = None
@@ -219,7 +218,9 @@ class compute(object):
                 else:
                     noises = list(self._noise((nsc, B, S, H, W)).unbind(0))
             train = F.photometric_train([outputs[("disp", s)].float() for s in opt.scales],
-                                        outputs[("P", opt.scales[0])], target, sources, inputs[("inv_K", 0)], ident,
+                                        (outputs[("P", opt.scales[0])] if opt.pose_type != "posecnn"
+                                         else [outputs[("P", s)] for s in opt.scales]),
+                                        target, sources, inputs[("inv_K", 0)], ident,
                                         noises, automask=automask, min_depth=opt.min_depth, max_depth=opt.max_depth,
                                         need_depth=(opt.scales[0] == 0))
             if train["depth"] is not None:

@@ -182,3 +182,36 @@ def test_smooth_loss_multi_vs_per_scale_and_golden(G):
         tot.backward()
         for s in range(c.n_scales):
             G.assert_close(d1[s].grad, d2[s].grad.cpu().numpy(), "smooth grad s%d" % s, rel=1e-6)
+
+
+def test_train_kernel_projection_per_scale(G):
+    """posecnn-style: a different projection for every scale (processor.py:153-157) -- against the per-scale kernels."""
+    B, H, W, S = 2, 64, 96, 2
+    colors, K, invK, Ts, rng = _synth_images(B, H, W, S, seed=11)
+    srcs = [G.t(x) for x in colors[1:]]
+    Kt = G.t(K)
+    ident = G.F.identity_loss(G.t(colors[0]), srcs)
+    disps_np = [rng.rand(B, 1, H >> s, W >> s).astype(np.float32) for s in range(3)]
+    noises = [G.t(rng.randn(B, S, H, W).astype(np.float32)) for _ in range(3)]
+    Ps_np = []
+    for s in range(3):
+        Tsc = [T.copy() for T in Ts]
+        for T in Tsc:
+            T[:, :3, 3] *= (1.0 + 0.5 * s)
+        Ps_np.append(torch.stack([G.F.compose_projection(Kt, G.t(T)) for T in Tsc]))
+    n = B * H * W
+    d1 = [G.t(x).requires_grad_(True) for x in disps_np]
+    P1 = [p.clone().requires_grad_(True) for p in Ps_np]
+    out = G.F.photometric_train(d1, P1, G.t(colors[0]), srcs, G.t(invK), ident, noises)
+    (out["sums"] * torch.tensor([1.0, 0.5, 0.25], device=G.DEV)).sum().div(n).backward()
+    d2 = [G.t(x).requires_grad_(True) for x in disps_np]
+    P2 = [p.clone().requires_grad_(True) for p in Ps_np]
+    tot = 0
+    for s in range(3):
+        o = G.F.photometric_scale(d2[s], P2[s], G.t(colors[0]), srcs, G.t(invK), ident, noises[s])
+        assert torch.equal(o["idx"], out["idx"][s])
+        tot = tot + o["sum"][0] * (0.5 ** s)
+    (tot / n).backward()
+    for s in range(3):
+        G.assert_close(d1[s].grad, d2[s].grad.cpu().numpy(), "grad disp s%d" % s)
+        G.assert_close(P1[s].grad, P2[s].grad.cpu().numpy(), "grad P s%d" % s)
