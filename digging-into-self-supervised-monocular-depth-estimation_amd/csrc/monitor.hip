@@ -29,7 +29,7 @@ struct MonArgs {
     float lo, hi;
     unsigned *hist;        // [2][MON_BINS]: gt, pred
     unsigned *sel;         // [8]: n, rank K, hi16(gt), rank in bin, hi16(pred), rank in bin, median bits gt, median bits pred
-    double *part;          // [blocks][6]
+    double *part;          // [blocks][7]
     float *out;            // [8]
     int premul;
 };
@@ -77,7 +77,6 @@ template <int LEVEL>
 __global__ __launch_bounds__(1024) void mon_select_kernel(MonArgs a)
 {
     __shared__ unsigned s_sum[1024];
-    __shared__ unsigned s_base;
     const int which = blockIdx.x;                   // 0: gt, 1: pred
     unsigned *h = a.hist + which * MON_BINS;
     constexpr int PER = MON_BINS / 1024;
