@@ -63,8 +63,8 @@ MDX_DEV float edge_weight(const float *__restrict__ c0, size_t hw, size_t i, siz
     float a0 = fabsf(c0[i] - c0[j]);
     float a1 = fabsf(c0[hw + i] - c0[hw + j]);
     float a2 = fabsf(c0[2 * hw + i] - c0[2 * hw + j]);
-    float g = ((a0 + a1) + a2) / 3.0f;
-    return expf(-g);
+    const float g = ((a0 + a1) + a2) * (1.0f / 3.0f);
+    return __expf(-g);      // hardware exponential: the smoothness term carries a 1e-4 tolerance, no pinned order
 }
 
 // partials layout per block: [0] sum_x, [1] sum_y, [2] dot(G, disp)   (block -> one image row band)
@@ -83,29 +83,30 @@ MDX_DEV void main_body(const float *__restrict__ disp, const float *__restrict__
     const size_t i = (size_t)bx * NT + threadIdx.x;
     if (i < hw) {
         const int y = (int)((unsigned)i / (unsigned)w), x = (int)((unsigned)i % (unsigned)w);
-        const float n0 = d[i] / m;
+        const float inv_m = 1.0f / m, inv_nx = 1.0f / (float)Nx, inv_ny = 1.0f / (float)Ny;
+        const float n0 = d[i] * inv_m;
         float gacc = 0.f;
         if (x + 1 < w) {
-            const float n1 = d[i + 1] / m;
+            const float n1 = d[i + 1] * inv_m;
             const float wg = edge_weight(c0, hw, i, i + 1);
             sx = (double)(fabsf(n0 - n1) * wg);
-            gacc += ((n0 > n1) ? 1.f : ((n0 < n1) ? -1.f : 0.f)) * wg / (float)Nx;
+            gacc += ((n0 > n1) ? 1.f : ((n0 < n1) ? -1.f : 0.f)) * wg * inv_nx;
         }
         if (x > 0) {
-            const float nm = d[i - 1] / m;
+            const float nm = d[i - 1] * inv_m;
             const float wg = edge_weight(c0, hw, i - 1, i);
-            gacc -= ((nm > n0) ? 1.f : ((nm < n0) ? -1.f : 0.f)) * wg / (float)Nx;
+            gacc -= ((nm > n0) ? 1.f : ((nm < n0) ? -1.f : 0.f)) * wg * inv_nx;
         }
         if (y + 1 < h) {
-            const float n1 = d[i + w] / m;
+            const float n1 = d[i + w] * inv_m;
             const float wg = edge_weight(c0, hw, i, i + w);
             sy = (double)(fabsf(n0 - n1) * wg);
-            gacc += ((n0 > n1) ? 1.f : ((n0 < n1) ? -1.f : 0.f)) * wg / (float)Ny;
+            gacc += ((n0 > n1) ? 1.f : ((n0 < n1) ? -1.f : 0.f)) * wg * inv_ny;
         }
         if (y > 0) {
-            const float nm = d[i - w] / m;
+            const float nm = d[i - w] * inv_m;
             const float wg = edge_weight(c0, hw, i - w, i);
-            gacc -= ((nm > n0) ? 1.f : ((nm < n0) ? -1.f : 0.f)) * wg / (float)Ny;
+            gacc -= ((nm > n0) ? 1.f : ((nm < n0) ? -1.f : 0.f)) * wg * inv_ny;
         }
         if (G) G[(size_t)b * hw + i] = gacc;
         dot = (double)gacc * (double)d[i];
@@ -132,6 +133,95 @@ __global__ __launch_bounds__(NT) void smooth_main_kernel(const float *__restrict
 }
 
 // one block: loss = sum_x/Nx + sum_y/Ny (parallel strided sums + LDS tree); per-image dot -> dots[b]
+// The same pass with FOUR consecutive pixels of a row per thread (w % 4 == 0): the rows y-1, y, y+1 of the disparity and
+// of the three colour planes come in as 16-byte loads plus the two columns either side (12 vector + 8 scalar loads for
+// four pixels instead of 80 scalar ones -- the one-pixel form is bound by load instructions: 30 us for 29 MB at scale 0),
+// and a horizontal edge weight is formed once for the two pixels it joins.
+MDX_DEV void main_body4(const float *__restrict__ disp, const float *__restrict__ color, const double *__restrict__ psum,
+                        int nchunk, int normalize, float *__restrict__ den, int B, int h, int w, float *__restrict__ G,
+                        double *__restrict__ part, int bx, int nbx, int b)
+{
+    __shared__ double s_red[3][NT / 64];
+    const size_t hw = (size_t)h * w;
+    const float *d = disp + (size_t)b * hw;
+    const float *c0 = color + (size_t)b * 3 * hw;
+    const float m = block_den(psum + (size_t)b * nchunk, nchunk, (int)hw, normalize, &s_red[0][0]);
+    if (bx == 0 && threadIdx.x == 0) den[b] = m;
+    const double Nx = (double)B * h * (w - 1), Ny = (double)B * (h - 1) * w;
+    double sx = 0.0, sy = 0.0, dot = 0.0;
+    const unsigned q = (unsigned)bx * NT + threadIdx.x;          // quad index inside the image
+    const unsigned wq = (unsigned)w / 4;
+    if (q < (unsigned)h * wq) {
+        const int y = (int)(q / wq), x = (int)(q - (unsigned)y * wq) * 4;
+        const float inv_m = 1.0f / m, inv_nx = 1.0f / (float)Nx, inv_ny = 1.0f / (float)Ny;
+        const size_t i = (size_t)y * w + x;
+        const bool up = y > 0, dn = y + 1 < h, lf = x > 0, rt = x + 4 < w;
+        // disparity: the row, its neighbours, the columns either side
+        const float4 dc = *reinterpret_cast<const float4 *>(d + i);
+        const float4 du = up ? *reinterpret_cast<const float4 *>(d + i - w) : dc;
+        const float4 dd = dn ? *reinterpret_cast<const float4 *>(d + i + w) : dc;
+        const float dl = lf ? d[i - 1] : 0.f, dr = rt ? d[i + 4] : 0.f;
+        const float n[6] = {dl * inv_m, dc.x * inv_m, dc.y * inv_m, dc.z * inv_m, dc.w * inv_m, dr * inv_m};
+        const float nu[4] = {du.x * inv_m, du.y * inv_m, du.z * inv_m, du.w * inv_m};
+        const float nd[4] = {dd.x * inv_m, dd.y * inv_m, dd.z * inv_m, dd.w * inv_m};
+        // edge weights exp(-mean_c |I_a - I_b|): five horizontal (x-1|x ... x+3|x+4), four up, four down
+        float gh[5] = {0, 0, 0, 0, 0}, gu[4] = {0, 0, 0, 0}, gd[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float *p = c0 + (size_t)c * hw + i;
+            const float4 cc = *reinterpret_cast<const float4 *>(p);
+            const float4 cu = up ? *reinterpret_cast<const float4 *>(p - w) : cc;
+            const float4 cd = dn ? *reinterpret_cast<const float4 *>(p + w) : cc;
+            const float cl = lf ? p[-1] : cc.x, cr = rt ? p[4] : cc.w;
+            const float row[6] = {cl, cc.x, cc.y, cc.z, cc.w, cr};
+#pragma unroll
+            for (int k = 0; k < 5; ++k) gh[k] += fabsf(row[k] - row[k + 1]);
+            gu[0] += fabsf(cu.x - cc.x); gu[1] += fabsf(cu.y - cc.y); gu[2] += fabsf(cu.z - cc.z); gu[3] += fabsf(cu.w - cc.w);
+            gd[0] += fabsf(cc.x - cd.x); gd[1] += fabsf(cc.y - cd.y); gd[2] += fabsf(cc.z - cd.z); gd[3] += fabsf(cc.w - cd.w);
+        }
+        float wh[5], wu[4], wd[4];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) wh[k] = __expf(-gh[k] * (1.0f / 3.0f));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { wu[k] = __expf(-gu[k] * (1.0f / 3.0f)); wd[k] = __expf(-gd[k] * (1.0f / 3.0f)); }
+        float4 gout;
+        float *go = &gout.x;
+        const float dv[4] = {dc.x, dc.y, dc.z, dc.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float n0 = n[k + 1];
+            float gacc = 0.f;
+            if (k < 3 || rt) {                                   // edge to the right neighbour
+                const float n1 = n[k + 2];
+                sx += (double)(fabsf(n0 - n1) * wh[k + 1]);
+                gacc += ((n0 > n1) ? 1.f : ((n0 < n1) ? -1.f : 0.f)) * wh[k + 1] * inv_nx;
+            }
+            if (k > 0 || lf) {                                   // edge to the left neighbour
+                const float nm = n[k];
+                gacc -= ((nm > n0) ? 1.f : ((nm < n0) ? -1.f : 0.f)) * wh[k] * inv_nx;
+            }
+            if (dn) {
+                sy += (double)(fabsf(n0 - nd[k]) * wd[k]);
+                gacc += ((n0 > nd[k]) ? 1.f : ((n0 < nd[k]) ? -1.f : 0.f)) * wd[k] * inv_ny;
+            }
+            if (up) gacc -= ((nu[k] > n0) ? 1.f : ((nu[k] < n0) ? -1.f : 0.f)) * wu[k] * inv_ny;
+            go[k] = gacc;
+            dot += (double)gacc * (double)dv[k];
+        }
+        if (G) *reinterpret_cast<float4 *>(G + (size_t)b * hw + i) = gout;
+    }
+    sx = wave_sum(sx); sy = wave_sum(sy); dot = wave_sum(dot);
+    if ((threadIdx.x & 63) == 0) {
+        s_red[0][threadIdx.x >> 6] = sx; s_red[1][threadIdx.x >> 6] = sy; s_red[2][threadIdx.x >> 6] = dot;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        double t = 0.0;
+        for (int k = 0; k < NT / 64; ++k) t += s_red[threadIdx.x][k];
+        part[((size_t)b * nbx + bx) * 3 + threadIdx.x] = t;
+    }
+}
+
 MDX_DEV void finish_body(const double *__restrict__ part, int B, int nblk, int h, int w, float *__restrict__ loss,
                          double *__restrict__ dots)
 {
@@ -179,6 +269,7 @@ __global__ __launch_bounds__(NT) void smooth_grad_kernel(float *__restrict__ G, 
 struct SmoothJobs {
     int nscales, B, normalize;
     int h[MDX_MAX_SCALES], w[MDX_MAX_SCALES], nblk[MDX_MAX_SCALES], nchunk[MDX_MAX_SCALES];
+    int vec[MDX_MAX_SCALES];          // 1: four pixels per thread (w % 4 == 0, 16-byte aligned planes); nblk counts those blocks
     int first_main[MDX_MAX_SCALES + 1], first_sum[MDX_MAX_SCALES + 1], first_grad[MDX_MAX_SCALES + 1];   // block ranges
     const float *disp[MDX_MAX_SCALES], *color[MDX_MAX_SCALES];
     float *gdisp[MDX_MAX_SCALES], *den[MDX_MAX_SCALES];
@@ -210,8 +301,12 @@ __global__ __launch_bounds__(NT) void smooth_multi_main_kernel(SmoothJobs j)
 {
     const int s = job_scale(j.first_main, blockIdx.x), rel = blockIdx.x - job_first(j.first_main, s);
     const int nb = spick(j.nblk, s);
-    main_body(spick(j.disp, s), spick(j.color, s), spick(j.psum, s), spick(j.nchunk, s), j.normalize, spick(j.den, s), j.B,
-              spick(j.h, s), spick(j.w, s), spick(j.gdisp, s), spick(j.part, s), rel % nb, nb, rel / nb);
+    if (spick(j.vec, s))
+        main_body4(spick(j.disp, s), spick(j.color, s), spick(j.psum, s), spick(j.nchunk, s), j.normalize, spick(j.den, s), j.B,
+                   spick(j.h, s), spick(j.w, s), spick(j.gdisp, s), spick(j.part, s), rel % nb, nb, rel / nb);
+    else
+        main_body(spick(j.disp, s), spick(j.color, s), spick(j.psum, s), spick(j.nchunk, s), j.normalize, spick(j.den, s), j.B,
+                  spick(j.h, s), spick(j.w, s), spick(j.gdisp, s), spick(j.part, s), rel % nb, nb, rel / nb);
 }
 
 __global__ __launch_bounds__(NT) void smooth_multi_finish_kernel(SmoothJobs j)
@@ -311,7 +406,9 @@ MDX_EXPORT int mdx_smooth_loss_multi(int nscales, int B, const int32_t *h, const
         if (h[ss] < 2 || w[ss] < 2 || (long long)B * h[ss] * w[ss] >= (1ll << 31)) return MDX_ERR_BAD_SHAPE;
         j.h[s] = h[ss]; j.w[s] = w[ss]; j.disp[s] = disp[ss]; j.color[s] = color[ss];
         j.gdisp[s] = gdisp ? gdisp[ss] : nullptr;
-        j.nblk[s] = (int)smooth_nblk(h[ss], w[ss]); j.nchunk[s] = (int)smooth_nchunk(h[ss], w[ss]);
+        j.vec[s] = (w[ss] % 4 == 0) && aligned(disp[ss], 16) && aligned(color[ss], 16) && (!gdisp || aligned(gdisp[ss], 16));
+        j.nblk[s] = j.vec[s] ? (int)(((size_t)h[ss] * (w[ss] / 4) + NT - 1) / NT) : (int)smooth_nblk(h[ss], w[ss]);
+        j.nchunk[s] = (int)smooth_nchunk(h[ss], w[ss]);
         if (s >= nscales) { j.den[s] = j.den[0]; j.dots[s] = j.dots[0]; j.part[s] = j.part[0]; j.psum[s] = j.psum[0]; continue; }
         const size_t den_bytes = ((size_t)B * sizeof(float) + 7) & ~(size_t)7;
         j.den[s] = (float *)ws;
