@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmdx_hip.so")
-SOURCES = ["photo_fwd.hip", "photo_bwd.hip", "photo_train.hip", "photo_abi.hip", "smooth.hip", "ops.hip", "glue.hip", "norm.hip", "pose.hip", "monitor.hip"]
+SOURCES = ["photo_fwd.hip", "photo_bwd.hip", "photo_train.hip", "photo_abi.hip", "smooth.hip", "ops.hip", "glue.hip", "norm.hip", "pose.hip", "monitor.hip", "imgproc.hip"]
 HEADERS = ["mdx_device.hpp", "mdx_common.hpp", "photo_common.hpp", "mdx_divtable.inc", os.path.join("..", "..", "include", "mdx.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # per-file additions.  photo_train.hip: the SLP vectorizer pairs neighbouring f32 ops into v_pk_* (no faster per element

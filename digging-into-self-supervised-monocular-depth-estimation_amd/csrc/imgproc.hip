@@ -1,0 +1,382 @@
+// imgproc.hip -- the per-sample image preparation of the KITTI loaders on the GPU, for gfx950.
+//
+// Reference call sites: model_loader/kitti_mono.py:288-291, 349-350 (transforms.Resize((H>>s, W>>s), ANTIALIAS) of the
+// ORIGINAL image for every scale), 302-303 (FLIP_LEFT_RIGHT), 284-285, 352-353 (ColorJitter), 283, 351 (ToTensor).
+// The arithmetic is Pillow's (not under /root/reference); these kernels reproduce it bit for bit:
+//   resample    Resample.c: Lanczos-3 weights in double, normalised, rounded to 22-bit fixed point (host: mdx_resample_plan);
+//               horizontal pass -> uint8 -> vertical pass -> uint8, each  clip8((2^21 + sum px*k) >> 22)
+//   jitter      ImageEnhance.Brightness / Contrast / Color = Blend.c's  a + alpha*(b - a)  in float32 with truncation
+//               (alpha in [0,1]) or clipping (outside); Contrast's grey level = int(mean(L) + 0.5) over the image;
+//               hue = Convert.c's rgb2hsv / hsv2rgb round trip (float/double mix) with the H byte shifted modulo 256
+//   ToTensor    float(u8) / 255.0f (IEEE division)
+// Byte / integer work, HBM- and L2-bound: no MFMA.  A CPU worker spends 3.7 ms decoding one 1242x375 JPEG and 41 ms
+// on the four resizes and the jitter of that frame (tools/loader_cost.py); with these kernels the workers only decode.
+//
+// Jobs travel BY VALUE in the kernel arguments (<= MDX_IMG_JOBS per launch): no device-side job table to keep alive,
+// nothing to copy, capturable.  Layouts: source = interleaved RGB rows as Pillow / the JPEG decoder hand them over
+// ([h][w][3] uint8, row stride in bytes); everything downstream is planar ([3][h][w]), the step's layout.
+#include <cmath>
+#include <cstring>
+#include "mdx_common.hpp"
+
+namespace mdx {
+
+constexpr int RS_BITS = 32 - 8 - 2;          // Resample.c PRECISION_BITS
+
+struct ResampleJobs {
+    mdx_resample_job j[MDX_IMG_JOBS];
+};
+struct JitterJobs {
+    mdx_jitter_job j[MDX_IMG_JOBS];
+};
+
+static __device__ __forceinline__ uint8_t clip8(int v)
+{
+    v >>= RS_BITS;
+    return (uint8_t)min(max(v, 0), 255);
+}
+
+// Horizontal pass: interleaved RGB [in_h][in_w][3] -> planar uint8 inter [3][in_h][out_w].
+// block = 64 output columns x 4 rows; the taps of one output column are contiguous source bytes (3 per tap).
+__global__ __launch_bounds__(256) void resample_h_kernel(ResampleJobs jobs)
+{
+    const mdx_resample_job &J = jobs.j[blockIdx.z];
+    const int xo = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (xo >= J.out_w || y >= J.in_h) return;
+    const int xmin = J.xbounds[2 * xo], n = J.xbounds[2 * xo + 1];
+    const int *k = J.xkk + (size_t)xo * J.xksize;
+    const uint8_t *row = J.src + (size_t)y * J.in_stride;
+    int s0 = 1 << (RS_BITS - 1), s1 = s0, s2 = s0;
+    if (J.flip) {
+        const uint8_t *p = row + 3 * (J.in_w - 1 - xmin);
+        for (int t = 0; t < n; ++t, p -= 3) {
+            const int c = k[t];
+            s0 += p[0] * c; s1 += p[1] * c; s2 += p[2] * c;
+        }
+    } else {
+        const uint8_t *p = row + 3 * xmin;
+        for (int t = 0; t < n; ++t, p += 3) {
+            const int c = k[t];
+            s0 += p[0] * c; s1 += p[1] * c; s2 += p[2] * c;
+        }
+    }
+    const size_t plane = (size_t)J.in_h * J.out_w, o = (size_t)y * J.out_w + xo;
+    J.inter[o] = clip8(s0);
+    J.inter[plane + o] = clip8(s1);
+    J.inter[2 * plane + o] = clip8(s2);
+}
+
+// Vertical pass: planar inter [3][in_h][out_w] -> planar [3][out_h][out_w] uint8 and / or float32 (= u8 / 255).
+// one thread per output byte, a wave reads 64 consecutive bytes of a row per tap.
+__global__ __launch_bounds__(256) void resample_v_kernel(ResampleJobs jobs)
+{
+    const mdx_resample_job &J = jobs.j[blockIdx.z / 3];
+    const int c = blockIdx.z % 3;
+    const int xo = blockIdx.x * 256 + threadIdx.x;
+    const int yo = blockIdx.y;
+    if (xo >= J.out_w || yo >= J.out_h) return;
+    const int ymin = J.ybounds[2 * yo], n = J.ybounds[2 * yo + 1];
+    const int *k = J.ykk + (size_t)yo * J.yksize;
+    const uint8_t *p = J.inter + ((size_t)c * J.in_h + ymin) * J.out_w + xo;
+    int s = 1 << (RS_BITS - 1);
+    for (int t = 0; t < n; ++t, p += J.out_w) s += p[0] * k[t];
+    const uint8_t v = clip8(s);
+    const size_t o = ((size_t)c * J.out_h + yo) * J.out_w + xo;
+    if (J.dst_u8) J.dst_u8[o] = v;
+    if (J.dst_f32) J.dst_f32[o] = (float)v / 255.0f;
+}
+
+// ---- per-pixel colour maps (Pillow's Convert.c / Blend.c arithmetic) ----
+struct RGB8 {
+    int r, g, b;
+};
+
+static __device__ __forceinline__ int rgb_to_L(const RGB8 &p)
+{
+    return (int)(((unsigned)p.r * 19595u + (unsigned)p.g * 38470u + (unsigned)p.b * 7471u + 0x8000u) >> 16);
+}
+
+// ImagingBlend(a, b, alpha) for one byte: float32 a + alpha*(b - a); `inside` = alpha in [0,1]
+static __device__ __forceinline__ int blend1(int a, int b, float alpha, bool inside)
+{
+    const float t = (float)a + alpha * (float)(b - a);
+    if (inside) return (int)(uint8_t)t;
+    return t <= 0.0f ? 0 : (t >= 255.0f ? 255 : (int)t);
+}
+
+static __device__ __forceinline__ RGB8 rgb2hsv(const RGB8 &p)
+{
+    const int maxc = max(p.r, max(p.g, p.b)), minc = min(p.r, min(p.g, p.b));
+    RGB8 o = {0, 0, maxc};
+    if (minc == maxc) return o;
+    const float cr = (float)(maxc - minc);
+    const float s = cr / (float)maxc;
+    const float rc = (float)(maxc - p.r) / cr, gc = (float)(maxc - p.g) / cr, bc = (float)(maxc - p.b) / cr;
+    float h;
+    if (p.r == maxc) h = bc - gc;
+    else if (p.g == maxc) h = (float)(2.0 + (double)rc - (double)bc);
+    else h = (float)(4.0 + (double)gc - (double)rc);
+    h = (float)fmod((double)h / 6.0 + 1.0, 1.0);
+    o.r = min(max((int)((double)h * 255.0), 0), 255);
+    o.g = min(max((int)((double)s * 255.0), 0), 255);
+    return o;
+}
+
+static __device__ __forceinline__ RGB8 hsv2rgb(const RGB8 &q)      // q.r = H, q.g = S, q.b = V
+{
+    const int v = q.b;
+    if (q.g == 0) return RGB8{v, v, v};
+    const double hf = (double)(float)q.r * 6.0 / 255.0;
+    const int i = (int)floor(hf);
+    const double f = (double)(float)(hf - (double)(float)i);
+    const double fs = (double)(float)((double)(float)q.g / 255.0);
+    const double vf = (double)(float)v;
+    const int p = min(max((int)round(vf * (1.0 - fs)), 0), 255);
+    const int qq = min(max((int)round(vf * (1.0 - fs * f)), 0), 255);
+    const int t = min(max((int)round(vf * (1.0 - fs * (1.0 - f))), 0), 255);
+    switch (i % 6) {
+    case 0: return RGB8{v, t, p};
+    case 1: return RGB8{qq, v, p};
+    case 2: return RGB8{p, v, t};
+    case 3: return RGB8{p, qq, v};
+    case 4: return RGB8{t, p, v};
+    default: return RGB8{v, p, qq};
+    }
+}
+
+// the adjustments order[first..last) applied to one pixel; `grey` = Contrast's degenerate level
+static __device__ __forceinline__ RGB8 jitter_ops(RGB8 p, const mdx_jitter_job &J, int first, int last, int grey)
+{
+    for (int i = first; i < last; ++i) {
+        const int op = J.order[i];
+        if (op == 0) {
+            const bool in = J.brightness >= 0.f && J.brightness <= 1.f;
+            p = RGB8{blend1(0, p.r, J.brightness, in), blend1(0, p.g, J.brightness, in), blend1(0, p.b, J.brightness, in)};
+        } else if (op == 1) {
+            const bool in = J.contrast >= 0.f && J.contrast <= 1.f;
+            p = RGB8{blend1(grey, p.r, J.contrast, in), blend1(grey, p.g, J.contrast, in), blend1(grey, p.b, J.contrast, in)};
+        } else if (op == 2) {
+            const bool in = J.saturation >= 0.f && J.saturation <= 1.f;
+            const int L = rgb_to_L(p);
+            p = RGB8{blend1(L, p.r, J.saturation, in), blend1(L, p.g, J.saturation, in), blend1(L, p.b, J.saturation, in)};
+        } else if (op == 3) {
+            RGB8 q = rgb2hsv(p);
+            q.r = (q.r + J.hue_shift) & 255;
+            p = hsv2rgb(q);
+        }
+    }
+    return p;
+}
+
+static __device__ __forceinline__ int contrast_slot(const mdx_jitter_job &J)
+{
+    for (int i = 0; i < 4; ++i)
+        if (J.order[i] == 1) return i;
+    return 4;
+}
+
+// Pass 1: sum of L over the image as it stands when Contrast is reached (exact integer sum; integer atomics).
+__global__ __launch_bounds__(256) void jitter_mean_kernel(JitterJobs jobs)
+{
+    const mdx_jitter_job &J = jobs.j[blockIdx.y];
+    const int n = J.h * J.w, slot = contrast_slot(J);
+    unsigned sum = 0;
+    if (slot < 4)
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+            RGB8 p = {J.src[i], J.src[(size_t)n + i], J.src[2 * (size_t)n + i]};
+            p = jitter_ops(p, J, 0, slot, 0);
+            sum += (unsigned)rgb_to_L(p);
+        }
+    __shared__ unsigned s_part[4];
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o, 64);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0 && slot < 4)
+        atomicAdd(J.lsum, (unsigned long long)s_part[0] + s_part[1] + s_part[2] + s_part[3]);
+}
+
+// Pass 2: the whole chain, planar uint8 in -> planar uint8 and / or float32 out.
+__global__ __launch_bounds__(256) void jitter_apply_kernel(JitterJobs jobs)
+{
+    const mdx_jitter_job &J = jobs.j[blockIdx.y];
+    const int n = J.h * J.w, slot = contrast_slot(J);
+    // ImageEnhance.Contrast: int(sum / count + 0.5) in double
+    const int grey = slot < 4 ? (int)((double)*J.lsum / (double)n + 0.5) : 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        RGB8 p = {J.src[i], J.src[(size_t)n + i], J.src[2 * (size_t)n + i]};
+        p = jitter_ops(p, J, 0, 4, grey);
+        if (J.dst_u8) {
+            J.dst_u8[i] = (uint8_t)p.r; J.dst_u8[(size_t)n + i] = (uint8_t)p.g; J.dst_u8[2 * (size_t)n + i] = (uint8_t)p.b;
+        }
+        if (J.dst_f32) {
+            J.dst_f32[i] = (float)p.r / 255.0f;
+            J.dst_f32[(size_t)n + i] = (float)p.g / 255.0f;
+            J.dst_f32[2 * (size_t)n + i] = (float)p.b / 255.0f;
+        }
+    }
+}
+
+// mode 0: RGB -> HSV, 1: HSV -> RGB, 2: RGB -> L (one plane out); planar [3][n] in
+__global__ __launch_bounds__(256) void color_convert_kernel(const uint8_t *src, uint8_t *dst, size_t n, int mode)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const RGB8 p = {src[i], src[n + i], src[2 * n + i]};
+    if (mode == 2) {
+        dst[i] = (uint8_t)rgb_to_L(p);
+        return;
+    }
+    const RGB8 o = mode == 0 ? rgb2hsv(p) : hsv2rgb(p);
+    dst[i] = (uint8_t)o.r; dst[n + i] = (uint8_t)o.g; dst[2 * n + i] = (uint8_t)o.b;
+}
+
+// ---- host side ----
+static double sinc_filter(double x)
+{
+    if (x == 0.0) return 1.0;
+    x = x * M_PI;
+    return sin(x) / x;
+}
+static double lanczos_filter(double x)
+{
+    if (-3.0 <= x && x < 3.0) return sinc_filter(x) * sinc_filter(x / 3);
+    return 0.0;
+}
+
+static int ksize_of(int in_size, int out_size)
+{
+    double filterscale = (double)in_size / out_size;
+    if (filterscale < 1.0) filterscale = 1.0;
+    return (int)ceil(3.0 * filterscale) * 2 + 1;
+}
+
+// does the plan (a device or host table we cannot read here) fit the job's sizes?  shapes only
+static int validate_resample(const mdx_resample_job &J)
+{
+    if (!J.src || !J.xbounds || !J.xkk || !J.ybounds || !J.ykk || !J.inter) return MDX_ERR_NULL_POINTER;
+    if (!J.dst_u8 && !J.dst_f32) return MDX_ERR_NULL_POINTER;
+    if (J.in_h <= 0 || J.in_w <= 0 || J.out_h <= 0 || J.out_w <= 0) return MDX_ERR_BAD_SHAPE;
+    if (J.in_h > 16384 || J.in_w > 16384 || J.out_h > 16384 || J.out_w > 16384) return MDX_ERR_BAD_SHAPE;
+    if (J.in_stride < 3 * J.in_w) return MDX_ERR_BAD_SHAPE;
+    if (J.xksize != ksize_of(J.in_w, J.out_w) || J.yksize != ksize_of(J.in_h, J.out_h)) return MDX_ERR_BAD_SHAPE;
+    if (J.dst_f32 && !aligned(J.dst_f32, 4)) return MDX_ERR_MISALIGNED;
+    if (!aligned(J.xbounds, 4) || !aligned(J.xkk, 4) || !aligned(J.ybounds, 4) || !aligned(J.ykk, 4))
+        return MDX_ERR_MISALIGNED;
+    return MDX_OK;
+}
+
+}  // namespace mdx
+
+using namespace mdx;
+
+MDX_EXPORT int mdx_resample_ksize(int in_size, int out_size)
+{
+    if (in_size <= 0 || out_size <= 0) return MDX_ERR_BAD_SHAPE;
+    return ksize_of(in_size, out_size);
+}
+
+// Resample.c precompute_coeffs (box = the whole axis) + normalize_coeffs_8bpc, into HOST arrays.
+MDX_EXPORT int mdx_resample_plan(int in_size, int out_size, int *bounds, int *kk)
+{
+    if (!bounds || !kk) return MDX_ERR_NULL_POINTER;
+    if (in_size <= 0 || out_size <= 0) return MDX_ERR_BAD_SHAPE;
+    const double scale = (double)in_size / out_size;
+    const double filterscale = scale < 1.0 ? 1.0 : scale;
+    const double support = 3.0 * filterscale;
+    const int ksize = (int)ceil(support) * 2 + 1;
+    const double ss = 1.0 / filterscale;
+    double *w = new double[ksize];
+    for (int xx = 0; xx < out_size; ++xx) {
+        const double center = (xx + 0.5) * scale;
+        int xmin = (int)(center - support + 0.5);
+        if (xmin < 0) xmin = 0;
+        int xmax = (int)(center + support + 0.5);
+        if (xmax > in_size) xmax = in_size;
+        xmax -= xmin;
+        double ww = 0.0;
+        for (int x = 0; x < xmax; ++x) {
+            w[x] = lanczos_filter((x + xmin - center + 0.5) * ss);
+            ww += w[x];
+        }
+        int *k = kk + (size_t)xx * ksize;
+        for (int x = 0; x < xmax; ++x) {
+            const double v = ww != 0.0 ? w[x] / ww : w[x];
+            k[x] = v < 0 ? (int)(-0.5 + v * (1 << RS_BITS)) : (int)(0.5 + v * (1 << RS_BITS));
+        }
+        for (int x = xmax; x < ksize; ++x) k[x] = 0;
+        bounds[2 * xx] = xmin;
+        bounds[2 * xx + 1] = xmax;
+    }
+    delete[] w;
+    return MDX_OK;
+}
+
+MDX_EXPORT int mdx_resample_lanczos_u8(const mdx_resample_job *jobs, int njobs, void *stream)
+{
+    if (!jobs) return MDX_ERR_NULL_POINTER;
+    if (njobs <= 0) return MDX_ERR_BAD_SHAPE;
+    for (int i = 0; i < njobs; ++i)
+        if (int rc = validate_resample(jobs[i])) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    for (int first = 0; first < njobs; first += MDX_IMG_JOBS) {
+        const int n = njobs - first < MDX_IMG_JOBS ? njobs - first : MDX_IMG_JOBS;
+        ResampleJobs a;
+        memset(&a, 0, sizeof(a));
+        int max_in_h = 0, max_out_w = 0, max_out_h = 0;
+        for (int i = 0; i < n; ++i) {
+            a.j[i] = jobs[first + i];
+            max_in_h = a.j[i].in_h > max_in_h ? a.j[i].in_h : max_in_h;
+            max_out_w = a.j[i].out_w > max_out_w ? a.j[i].out_w : max_out_w;
+            max_out_h = a.j[i].out_h > max_out_h ? a.j[i].out_h : max_out_h;
+        }
+        hipLaunchKernelGGL(resample_h_kernel, dim3((max_out_w + 63) / 64, (max_in_h + 3) / 4, n), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(resample_v_kernel, dim3((max_out_w + 255) / 256, max_out_h, 3 * n), dim3(256), 0, st, a);
+    }
+    return check_launch();
+}
+
+MDX_EXPORT int mdx_color_jitter_u8(const mdx_jitter_job *jobs, int njobs, void *stream)
+{
+    if (!jobs) return MDX_ERR_NULL_POINTER;
+    if (njobs <= 0) return MDX_ERR_BAD_SHAPE;
+    for (int i = 0; i < njobs; ++i) {
+        const mdx_jitter_job &J = jobs[i];
+        if (!J.src || !J.lsum || (!J.dst_u8 && !J.dst_f32)) return MDX_ERR_NULL_POINTER;
+        if (J.h <= 0 || J.w <= 0 || (long long)J.h * J.w > (1ll << 24)) return MDX_ERR_BAD_SHAPE;   // L sums fit uint32 per thread
+        if (!aligned(J.lsum, 8) || (J.dst_f32 && !aligned(J.dst_f32, 4))) return MDX_ERR_MISALIGNED;
+        unsigned seen = 0;
+        for (int k = 0; k < 4; ++k) {
+            if (J.order[k] < 0 || J.order[k] > 4) return MDX_ERR_UNSUPPORTED;     // 4 = skip this slot
+            if (J.order[k] < 4 && (seen >> J.order[k] & 1u)) return MDX_ERR_UNSUPPORTED;
+            if (J.order[k] < 4) seen |= 1u << J.order[k];
+        }
+    }
+    hipStream_t st = (hipStream_t)stream;
+    for (int first = 0; first < njobs; first += MDX_IMG_JOBS) {
+        const int n = njobs - first < MDX_IMG_JOBS ? njobs - first : MDX_IMG_JOBS;
+        JitterJobs a;
+        memset(&a, 0, sizeof(a));
+        int max_px = 0;
+        for (int i = 0; i < n; ++i) {
+            a.j[i] = jobs[first + i];
+            max_px = a.j[i].h * a.j[i].w > max_px ? a.j[i].h * a.j[i].w : max_px;
+            if (hipMemsetAsync(a.j[i].lsum, 0, sizeof(unsigned long long), st) != hipSuccess) return MDX_ERR_LAUNCH;
+        }
+        int blocks = (max_px + 255) / 256;
+        if (blocks > 120) blocks = 120;             // 120 blocks x <=32 jobs fill the chip; the loops stride
+        hipLaunchKernelGGL(jitter_mean_kernel, dim3(blocks, n), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(jitter_apply_kernel, dim3(blocks, n), dim3(256), 0, st, a);
+    }
+    return check_launch();
+}
+
+MDX_EXPORT int mdx_color_convert_u8(int mode, const uint8_t *src, uint8_t *dst, size_t npix, void *stream)
+{
+    if (!src || !dst) return MDX_ERR_NULL_POINTER;
+    if (mode < 0 || mode > 2) return MDX_ERR_UNSUPPORTED;
+    if (npix == 0 || npix > ((size_t)1 << 31)) return MDX_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(color_convert_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src,
+                       dst, npix, mode);
+    return check_launch();
+}

@@ -30,8 +30,9 @@ def to_tensor(img, uint8=False):
     """ToTensor: [3,H,W] float32 in [0,1] (x / 255).  uint8=True leaves the division to the consumer
     (compute.forward_depth does it on the GPU, same correctly rounded x / 255): a quarter of the bytes go through the
     worker -> shared memory -> pinned memory -> PCIe pipeline."""
-    t = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1)
-    return t.contiguous() if uint8 else t.float().div_(255.0)
+    if uint8:   # numpy's transposing copy: 0.16 ms; torch's permute().contiguous() on uint8 takes 48 ms for 640x192
+        return torch.from_numpy(np.ascontiguousarray(np.asarray(img, dtype=np.uint8).transpose(2, 0, 1)))
+    return torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).float().div_(255.0)
 
 
 class ColorJitter(object):

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MDX_VERSION 200
+#define MDX_VERSION 210
 #define MDX_MAX_SRC 4
 #define MDX_MAX_SCALES 4
 
@@ -298,6 +298,49 @@ size_t mdx_depth_monitor_workspace_bytes(int B, int r0, int r1, int c0, int c1);
 int mdx_depth_monitor(const float *pred, int B, int h, int w, const float *gt, int gh, int gw, int r0, int r1, int c0,
                       int c1, float min_depth, float max_depth, float *out, void *workspace, size_t workspace_bytes,
                       void *stream);
+
+/* ---- image preparation on the GPU   replaces, per sample and frame, the Pillow / torchvision calls of
+ * model_loader/kitti_mono.py:288-291 + 349-353 (transforms.Resize((H>>s, W>>s), Image.ANTIALIAS) of the original image
+ * for every scale, ColorJitter, ToTensor) and kitti_mono.py:302-303 (FLIP_LEFT_RIGHT); same in kitti_stereo.py.
+ * Bit-exact with Pillow (Resample.c, Blend.c, Convert.c, ImageEnhance.py) -- uint8 results, float32 = u8 / 255.
+ * Jobs are HOST arrays of plain structs whose pointers are DEVICE pointers (except where noted); they are passed to the
+ * kernels by value, MDX_IMG_JOBS per launch, so the caller may free or reuse the array on return. */
+#define MDX_IMG_JOBS 32
+
+/* taps per output sample of the Lanczos-3 plan in_size -> out_size (2*ceil(3*max(in/out,1)) + 1) */
+int mdx_resample_ksize(int in_size, int out_size);
+/* Resample.c precompute_coeffs + normalize_coeffs_8bpc: bounds [out_size][2] = (first source sample, number of taps),
+ * kk [out_size][ksize] = 22-bit fixed-point weights.  HOST arrays (the caller uploads and caches them per size pair). */
+int mdx_resample_plan(int in_size, int out_size, int *bounds, int *kk);
+
+typedef struct mdx_resample_job {
+    const uint8_t *src;          /* interleaved RGB, rows of in_stride bytes (>= 3*in_w): the decoder's layout */
+    const int *xbounds, *xkk;    /* plan in_w -> out_w (device copies) */
+    const int *ybounds, *ykk;    /* plan in_h -> out_h */
+    uint8_t *inter;              /* scratch, planar [3][in_h][out_w] */
+    uint8_t *dst_u8;             /* planar [3][out_h][out_w], or NULL */
+    float *dst_f32;              /* planar [3][out_h][out_w] = u8 / 255 (ToTensor), or NULL */
+    int in_h, in_w, in_stride, flip;   /* flip: resize image.transpose(FLIP_LEFT_RIGHT) */
+    int out_h, out_w, xksize, yksize;
+} mdx_resample_job;
+/* Image.resize((out_w, out_h), Image.LANCZOS): horizontal pass to uint8, then vertical pass. */
+int mdx_resample_lanczos_u8(const mdx_resample_job *jobs, int njobs, void *stream);
+
+typedef struct mdx_jitter_job {
+    const uint8_t *src;          /* planar [3][h][w] */
+    float *dst_f32;              /* planar [3][h][w] = u8 / 255, or NULL */
+    uint8_t *dst_u8;             /* planar, or NULL (may alias src: each pixel is read before it is written) */
+    unsigned long long *lsum;    /* scratch, one 8-byte word per job (sum of L for Contrast) */
+    int h, w;
+    int order[4];                /* 0 brightness, 1 contrast, 2 saturation, 3 hue, 4 = empty slot; each at most once */
+    int hue_shift;               /* int(hue_factor * 255), added to the H byte modulo 256 */
+    float brightness, contrast, saturation;   /* ImageEnhance factors */
+} mdx_jitter_job;
+/* torchvision ColorJitter on PIL images: the adjustments in `order`, uint8 after each. */
+int mdx_color_jitter_u8(const mdx_jitter_job *jobs, int njobs, void *stream);
+
+/* Unfused parity op: Pillow's convert() maps on planar uint8 [3][npix]: mode 0 RGB->HSV, 1 HSV->RGB, 2 RGB->L ([npix] out). */
+int mdx_color_convert_u8(int mode, const uint8_t *src, uint8_t *dst, size_t npix, void *stream);
 
 #ifdef __cplusplus
 }

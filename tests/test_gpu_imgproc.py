@@ -1,0 +1,160 @@
+"""GPU parity of csrc/imgproc.hip (the KITTI loaders' Pillow resizes, colour jitter and ToTensor):
+bit-exact against the numpy oracle (oracle/imgproc.py) and against the installed Pillow itself."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import imgproc as orc
+
+pytestmark = pytest.mark.gpu
+PIL = pytest.importorskip("PIL")
+from PIL import Image  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def G():
+    import gpu_util
+    return gpu_util
+
+
+@pytest.fixture(scope="module")
+def IP(G):
+    from mdx import imgproc
+    return imgproc
+
+
+def _natural(rng, h, w):
+    """smooth structure + noise, uint8 [h,w,3] (white noise alone never exercises the clipping of Lanczos overshoot)"""
+    lo = rng.random((max(h // 8, 2), max(w // 8, 2), 3))
+    img = np.asarray(Image.fromarray((lo * 255).astype(np.uint8)).resize((w, h), Image.BICUBIC)).astype(np.int32)
+    img = img + rng.integers(-12, 13, img.shape)
+    img[: h // 4, : w // 4] = rng.integers(0, 2, (h // 4, w // 4, 1)) * 255        # hard edges: overshoot -> clip8
+    return img.clip(0, 255).astype(np.uint8)
+
+
+def _stack(imgs):
+    hmax, wmax = max(i.shape[0] for i in imgs), max(i.shape[1] for i in imgs)
+    out = np.zeros((len(imgs), hmax, wmax, 3), np.uint8)
+    for n, i in enumerate(imgs):
+        out[n, : i.shape[0], : i.shape[1]] = i
+    return out
+
+
+def _pil_resize(img, oh, ow, flip):
+    im = Image.fromarray(img)
+    if flip:
+        im = im.transpose(Image.FLIP_LEFT_RIGHT)
+    return np.asarray(im.resize((ow, oh), Image.LANCZOS))
+
+
+@pytest.mark.parametrize("case", [
+    dict(sizes=[(375, 1242)] * 3, out=(192, 640)),
+    dict(sizes=[(375, 1242), (370, 1226), (376, 1241), (374, 1238)], out=(96, 320)),       # KITTI's sizes, one batch
+    dict(sizes=[(375, 1242), (370, 1226)], out=(24, 80)),                                  # 95 taps
+    dict(sizes=[(375, 1242), (376, 1241)], out=(320, 1024)),                               # BASELINE configs[3]
+    dict(sizes=[(20, 30), (17, 30)], out=(40, 60)),                                        # upscale
+    dict(sizes=[(48, 64)], out=(48, 64)),                                                  # identity plan
+    dict(sizes=[(50, 50)], out=(50, 25)),
+    dict(sizes=[(33, 47)] * 37, out=(16, 24)),                                             # > MDX_IMG_JOBS jobs
+])
+def test_resize_lanczos_bit_exact(G, IP, case):
+    rng = np.random.default_rng(len(case["sizes"]) * 1000 + case["out"][1])
+    imgs = [_natural(rng, h, w) for (h, w) in case["sizes"]]
+    flips = [bool(n % 2) for n in range(len(imgs))]
+    oh, ow = case["out"]
+    plans = IP.plan_cache("cuda:0")
+    u8, f32 = IP.resize_lanczos(plans, torch.from_numpy(_stack(imgs)).cuda(), case["sizes"], flips, (oh, ow), want_u8=True)
+    u8, f32 = u8.cpu().numpy(), f32.cpu().numpy()
+    for n, img in enumerate(imgs):
+        ref = orc.resample_lanczos(img, oh, ow, flips[n])
+        assert np.array_equal(ref, _pil_resize(img, oh, ow, flips[n]))                      # oracle == Pillow
+        assert np.array_equal(u8[n], ref.transpose(2, 0, 1)), "image %d" % n
+        assert np.array_equal(f32[n].view(np.uint32), orc.to_tensor(ref).view(np.uint32)), "ToTensor %d" % n
+
+
+def test_color_maps_exhaustive(G, IP):
+    """every RGB triple through RGB->HSV and RGB->L, every HSV triple through HSV->RGB: equal to Pillow's convert()."""
+    grid = np.stack(np.meshgrid(np.arange(256), np.arange(256), np.arange(256), indexing="ij"), -1)
+    grid = grid.reshape(4096, 4096, 3).astype(np.uint8)
+    planar = torch.from_numpy(np.ascontiguousarray(grid.reshape(-1, 3).T)).cuda()
+    im = Image.fromarray(grid)
+    for mode, ref in (("hsv", np.asarray(im.convert("HSV"))), ("rgb", np.asarray(Image.fromarray(grid, "HSV").convert("RGB")))):
+        got = IP.color_convert(planar, mode).cpu().numpy().T.reshape(4096, 4096, 3)
+        assert np.array_equal(got, ref), mode
+    got = IP.color_convert(planar, "L").cpu().numpy().reshape(4096, 4096)
+    assert np.array_equal(got, np.asarray(im.convert("L")))
+    sub = np.ascontiguousarray(grid[::37, ::41])
+    assert np.array_equal(orc.rgb2hsv(sub), np.asarray(Image.fromarray(sub).convert("HSV")))
+
+
+def test_color_jitter_bit_exact(G, IP):
+    """30 draws of (order, factors) in the loader's ranges + factors inside [0,1] (truncation branch) and partial
+    orders; against the oracle and the loader's Pillow ColorJitter."""
+    from model_loader.kitti import ColorJitter
+    rng = np.random.default_rng(5)
+    imgs = [_natural(rng, 48, 96) for _ in range(34)]
+    params, refs = [], []
+    for n, img in enumerate(imgs):
+        if n == 7:
+            params.append(None)
+            refs.append(None)
+            continue
+        j = ColorJitter(random.Random(n))
+        if n >= 30:
+            j.b, j.c, j.s = 0.3 + 0.1 * (n - 30), 0.9, 0.55
+            j.order = j.order[: 2 + (n - 30) % 3]
+        p = (j.order, j.b, j.c, j.s, int(j.h * 255))
+        params.append(p)
+        ref = orc.color_jitter(img, *p)
+        assert np.array_equal(ref, np.asarray(j(Image.fromarray(img))))                      # oracle == Pillow chain
+        refs.append(ref)
+    src = torch.from_numpy(np.stack([i.transpose(2, 0, 1) for i in imgs])).contiguous().cuda()
+    out = torch.full((len(imgs), 3, 48, 96), -1.0, device="cuda")
+    IP.color_jitter(src, params, out)
+    out = out.cpu().numpy()
+    assert (out[7] == -1.0).all()                                                            # untouched without params
+    for n, ref in enumerate(refs):
+        if ref is not None:
+            assert np.array_equal(out[n].view(np.uint32), orc.to_tensor(ref).view(np.uint32)), "image %d" % n
+
+
+def test_image_prep_equals_cpu_loader_arithmetic(G, IP):
+    """the batch-level stage against what the CPU loader computes per sample with Pillow (model_loader/kitti.py)."""
+    from model_loader.kitti import ColorJitter, to_tensor
+    rng = np.random.default_rng(9)
+    B, frames, sizes = 3, [0, -1, 1], [(375, 1242), (370, 1226), (376, 1241)]
+    raw = {f: [_natural(rng, h, w) for (h, w) in sizes] for f in frames}
+    flips = [False, True, False]
+    jit = [ColorJitter(random.Random(3)), None, ColorJitter(random.Random(4))]
+    rows = [[0.0] * 9 if j is None else [1.0] + list(j.order) + [j.b, j.c, j.s, int(j.h * 255)] for j in jit]
+    batch = {("raw", f): torch.from_numpy(_stack(raw[f])) for f in frames}
+    batch.update({"raw_size": torch.tensor(sizes, dtype=torch.int32), "raw_flip": torch.tensor(flips),
+                  "raw_jitter": torch.tensor(rows, dtype=torch.float64), ("K", 0): torch.eye(4).repeat(B, 1, 1)})
+    prep = IP.image_prep(192, 640, frames, 4, "cuda:0")
+    out = prep(batch)
+    assert ("raw", 0) not in out and "raw_size" not in out and ("K", 0) in out
+    for f in frames:
+        for b in range(B):
+            im = Image.fromarray(raw[f][b])
+            if flips[b]:
+                im = im.transpose(Image.FLIP_LEFT_RIGHT)
+            for s in range(4 if f == 0 else 1):
+                small = im.resize((640 >> s, 192 >> s), Image.LANCZOS)
+                assert torch.equal(out[("color", f, s)][b].cpu(), to_tensor(small)), (f, b, s)
+                if s == 0:
+                    aug = to_tensor(jit[b](small)) if jit[b] is not None else to_tensor(small)
+                    assert torch.equal(out[("color_aug", f, 0)][b].cpu(), aug), (f, b)
+    assert ("color", -1, 1) not in out and ("color_aug", 0, 1) not in out
+
+
+def test_imgproc_refuses_bad_input(G, IP):
+    from mdx._lib import MdxError
+    plans = IP.plan_cache("cuda:0")
+    with pytest.raises(MdxError):
+        IP.resize_lanczos(plans, torch.zeros(1, 8, 8, 3, dtype=torch.uint8), [(8, 8)], [False], (4, 4))     # CPU tensor
+    with pytest.raises(MdxError):
+        IP.resize_lanczos(plans, torch.zeros(1, 8, 8, 3, dtype=torch.uint8).cuda(), [(9, 8)], [False], (4, 4))
+    with pytest.raises(MdxError):
+        IP.color_jitter(torch.zeros(1, 3, 8, 8, dtype=torch.uint8).cuda(), [([0, 0, 1, 2], 1.0, 1.0, 1.0, 0)])
