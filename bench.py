@@ -232,6 +232,8 @@ def trainer_loop(args, frame_ids, steps, warmup, workers):
     opt.uint8_loader = not args.float_loader     # colours uint8 through the host pipeline, x/255 on the GPU
     opt.collate_step_keys = not args.float_loader
     opt.graph = not args.trainer_eager
+    # decoded KITTI-sized frames through the loader; flip / Lanczos pyramid / jitter / ToTensor on the GPU (csrc/imgproc.hip)
+    opt.synthetic_raw, opt.gpu_image_prep = bool(args.raw_frames), "true" if args.raw_frames else "false"
     opt.max_steps, opt.miopen_find = 0, args.miopen_find
     if os.environ.get("MDX_SWITCH_INTERVAL"):
         sys.setswitchinterval(float(os.environ["MDX_SWITCH_INTERVAL"]))
@@ -252,7 +254,8 @@ def trainer_loop(args, frame_ids, steps, warmup, workers):
     vals = {k: tr.control._mean(v) for k, v in log.items()}
     del it
     return {"value": args.batch * steps / dt, "unit": "images/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
-            "workers": workers, "uint8_loader": bool(opt.uint8_loader), "hip_graph": bool(opt.graph), "what": "model_train.trainer: DataLoader (pinned, side-stream upload) -> train_step -> "
+            "workers": workers, "uint8_loader": bool(opt.uint8_loader), "hip_graph": bool(opt.graph),
+            "raw_frames": bool(args.raw_frames), "what": "model_train.trainer: DataLoader (pinned, side-stream upload) -> train_step -> "
                                         "control.metric every step", "abs_rel_monitor": vals.get("abs_rel")}
 
 
@@ -281,6 +284,9 @@ def main():
                     help="trainer loop with the reference's float32 colours through the DataLoader (4x the host bytes)")
     ap.add_argument("--trainer-eager", action="store_true",
                     help="trainer loop without the hipGraph replay of the step (model_option --graph 0)")
+    ap.add_argument("--raw-frames", action="store_true",
+                    help="trainer loop fed with decoded 1242x375 frames (what the KITTI loaders hand over with "
+                         "--gpu_image_prep): the Lanczos pyramid, the colour jitter and ToTensor run on the GPU")
     ap.add_argument("--workers", type=int, default=12, help="DataLoader workers of the trainer-loop measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")

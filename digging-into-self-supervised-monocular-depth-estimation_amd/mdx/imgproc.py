@@ -20,19 +20,19 @@ import torch
 from . import _lib
 
 IMG_JOBS = 32
+JITTER_PARTIALS = 128      # MDX_JITTER_PARTIALS
 
 
-class ResampleJob(C.Structure):      # mdx_resample_job
-    _fields_ = [("src", C.c_void_p), ("xbounds", C.c_void_p), ("xkk", C.c_void_p), ("ybounds", C.c_void_p),
-                ("ykk", C.c_void_p), ("inter", C.c_void_p), ("dst_u8", C.c_void_p), ("dst_f32", C.c_void_p),
-                ("in_h", C.c_int32), ("in_w", C.c_int32), ("in_stride", C.c_int32), ("flip", C.c_int32),
-                ("out_h", C.c_int32), ("out_w", C.c_int32), ("xksize", C.c_int32), ("yksize", C.c_int32)]
-
-
-class JitterJob(C.Structure):        # mdx_jitter_job
-    _fields_ = [("src", C.c_void_p), ("dst_f32", C.c_void_p), ("dst_u8", C.c_void_p), ("lsum", C.c_void_p),
-                ("h", C.c_int32), ("w", C.c_int32), ("order", C.c_int32 * 4), ("hue_shift", C.c_int32),
-                ("brightness", C.c_float), ("contrast", C.c_float), ("saturation", C.c_float)]
+# mdx_resample_job / mdx_jitter_job as numpy records (same layout: pointers first, no padding) -- a batch has ~110 jobs
+# and filling ctypes structures field by field cost 0.5 ms of host time per step; whole columns are assigned instead
+RESAMPLE_JOB = np.dtype([("src", "<u8"), ("xbounds", "<u8"), ("xkk", "<u8"), ("ybounds", "<u8"), ("ykk", "<u8"),
+                         ("inter", "<u8"), ("dst_u8", "<u8"), ("dst_f32", "<u8"),
+                         ("in_h", "<i4"), ("in_w", "<i4"), ("in_stride", "<i4"), ("flip", "<i4"),
+                         ("out_h", "<i4"), ("out_w", "<i4"), ("xksize", "<i4"), ("yksize", "<i4")])
+JITTER_JOB = np.dtype([("src", "<u8"), ("dst_f32", "<u8"), ("dst_u8", "<u8"), ("lsum", "<u8"),
+                       ("h", "<i4"), ("w", "<i4"), ("order", "<i4", (4,)), ("hue_shift", "<i4"),
+                       ("brightness", "<f4"), ("contrast", "<f4"), ("saturation", "<f4")])
+assert RESAMPLE_JOB.itemsize == 96 and JITTER_JOB.itemsize == 72
 
 
 def _check_u8(t, what):
@@ -55,46 +55,66 @@ class plan_cache(object):
             if ksize <= 0:
                 _lib.check(ksize, "mdx_resample_ksize")
             bounds = np.zeros((key[1], 2), np.int32)
-            kk = np.zeros((key[1], ksize), np.int32)
+            kk = np.zeros((ksize, key[1]), np.int32)          # tap-major (include/mdx.h)
             _lib.check(lib.mdx_resample_plan(key[0], key[1], bounds.ctypes.data_as(C.c_void_p),
                                              kk.ctypes.data_as(C.c_void_p)), "mdx_resample_plan")
             self.plans[key] = (ksize, torch.from_numpy(bounds).to(self.device), torch.from_numpy(kk).to(self.device))
         return self.plans[key]
 
 
-def resize_lanczos(plans, src, sizes, flips, out_hw, want_u8=False, want_f32=True):
-    """Image.resize((out_w, out_h), Image.LANCZOS) of N images in one call.
-    src uint8 [N, hmax, wmax, 3] (image n occupies [:h_n, :w_n]); sizes [(h, w)] * N; flips [bool] * N.
-    -> (uint8 [N,3,out_h,out_w] or None, float32 [N,3,out_h,out_w] = u8 / 255 or None)."""
-    _check_u8(src, "src")
-    N, hmax, wmax = src.shape[0], src.shape[1], src.shape[2]
-    if src.shape[3] != 3 or len(sizes) != N or len(flips) != N:
-        raise _lib.MdxError("resize_lanczos: src [N,h,w,3] with N sizes and N flips expected")
-    oh, ow = int(out_hw[0]), int(out_hw[1])
-    dev = src.device
-    u8 = torch.empty(N, 3, oh, ow, dtype=torch.uint8, device=dev) if want_u8 else None
-    f32 = torch.empty(N, 3, oh, ow, dtype=torch.float32, device=dev) if want_f32 else None
-    inter = torch.empty(N, 3 * hmax * ow, dtype=torch.uint8, device=dev)
-    jobs = (ResampleJob * N)()
-    keep = []
-    for n in range(N):
-        h, w = int(sizes[n][0]), int(sizes[n][1])
-        if not (0 < h <= hmax and 0 < w <= wmax):
-            raise _lib.MdxError("resize_lanczos: image %d has size %dx%d inside a %dx%d slot" % (n, h, w, hmax, wmax))
-        kx, xb, xk = plans.get(w, ow)
-        ky, yb, yk = plans.get(h, oh)
-        keep += [xb, xk, yb, yk]
-        j = jobs[n]
-        j.src = src[n].data_ptr()
-        j.xbounds, j.xkk, j.ybounds, j.ykk = xb.data_ptr(), xk.data_ptr(), yb.data_ptr(), yk.data_ptr()
-        j.inter = inter[n].data_ptr()
-        j.dst_u8 = u8[n].data_ptr() if want_u8 else None
-        j.dst_f32 = f32[n].data_ptr() if want_f32 else None
-        j.in_h, j.in_w, j.in_stride, j.flip = h, w, 3 * wmax, int(bool(flips[n]))
-        j.out_h, j.out_w, j.xksize, j.yksize = oh, ow, kx, ky
-    _lib.check(_lib.lib().mdx_resample_lanczos_u8(jobs, N, _lib.stream()), "mdx_resample_lanczos_u8")
+def resize_lanczos_multi(plans, sources, sizes, flips, outs):
+    """Image.resize((out_w, out_h), Image.LANCZOS) for several blocks of images and several output sizes in ONE call.
+    sources: list of uint8 [N, hmax, wmax, 3] (image n occupies [:h_n, :w_n]); sizes [(h, w)] * N and flips [bool] * N
+    hold for every block (the frames of a sample share them).  outs: list of (block index, (out_h, out_w), want_u8,
+    want_f32) -> list of (uint8 [N,3,out_h,out_w] or None, float32 [N,3,out_h,out_w] = u8 / 255 or None)."""
+    N = len(sizes)
+    for src in sources:
+        _check_u8(src, "src")
+        if src.dim() != 4 or src.shape[0] != N or src.shape[3] != 3 or len(flips) != N:
+            raise _lib.MdxError("resize_lanczos: src [N,h,w,3] with N sizes and N flips expected")
+    dev = sources[0].device
+    jobs = np.zeros(N * len(outs), RESAMPLE_JOB)
+    results, keep, scratch = [], [], 0
+    for (si, (oh, ow), want_u8, want_f32) in outs:
+        scratch += N * 3 * sources[si].shape[1] * int(ow)
+    inter = torch.empty(scratch, dtype=torch.uint8, device=dev)
+    hs = np.array([int(s[0]) for s in sizes], np.int64)
+    ws = np.array([int(s[1]) for s in sizes], np.int64)
+    fl = np.array([int(bool(f)) for f in flips], np.int32)
+    idx = np.arange(N, dtype=np.uint64)
+    at = 0
+    for o, (si, (oh, ow), want_u8, want_f32) in enumerate(outs):
+        src = sources[si]
+        hmax, wmax = src.shape[1], src.shape[2]
+        oh, ow = int(oh), int(ow)
+        if hs.min() <= 0 or ws.min() <= 0 or hs.max() > hmax or ws.max() > wmax:
+            raise _lib.MdxError("resize_lanczos: an image of %s does not fit its %dx%d slot" % (sizes, hmax, wmax))
+        u8 = torch.empty(N, 3, oh, ow, dtype=torch.uint8, device=dev) if want_u8 else None
+        f32 = torch.empty(N, 3, oh, ow, dtype=torch.float32, device=dev) if want_f32 else None
+        results.append((u8, f32))
+        j = jobs[o * N:(o + 1) * N]
+        xp = [plans.get(int(w), ow) for w in ws]
+        yp = [plans.get(int(h), oh) for h in hs]
+        keep += [xp, yp]
+        j["src"] = src.data_ptr() + idx * np.uint64(hmax * wmax * 3)
+        j["xbounds"], j["xkk"] = [p[1].data_ptr() for p in xp], [p[2].data_ptr() for p in xp]
+        j["ybounds"], j["ykk"] = [p[1].data_ptr() for p in yp], [p[2].data_ptr() for p in yp]
+        j["inter"] = inter.data_ptr() + at + idx * np.uint64(3 * hmax * ow)
+        at += N * 3 * hmax * ow
+        j["dst_u8"] = u8.data_ptr() + idx * np.uint64(3 * oh * ow) if want_u8 else 0
+        j["dst_f32"] = f32.data_ptr() + idx * np.uint64(12 * oh * ow) if want_f32 else 0
+        j["in_h"], j["in_w"], j["in_stride"], j["flip"] = hs, ws, 3 * wmax, fl
+        j["out_h"], j["out_w"] = oh, ow
+        j["xksize"], j["yksize"] = [p[0] for p in xp], [p[0] for p in yp]
+    _lib.check(_lib.lib().mdx_resample_lanczos_u8(jobs.ctypes.data_as(C.c_void_p), len(jobs), _lib.stream()),
+               "mdx_resample_lanczos_u8")
     inter.record_stream(torch.cuda.current_stream(dev))
-    return u8, f32
+    return results
+
+
+def resize_lanczos(plans, src, sizes, flips, out_hw, want_u8=False, want_f32=True):
+    """one block, one output size: -> (uint8 [N,3,out_h,out_w] or None, float32 = u8 / 255 or None)."""
+    return resize_lanczos_multi(plans, [src], sizes, flips, [(0, out_hw, want_u8, want_f32)])[0]
 
 
 def color_jitter(src_u8, params, out=None):
@@ -109,17 +129,21 @@ def color_jitter(src_u8, params, out=None):
     todo = [n for n in range(N) if params[n] is not None]
     if not todo:
         return out
-    lsum = torch.empty(len(todo), dtype=torch.int64, device=dev)
-    jobs = (JitterJob * len(todo))()
+    lsum = torch.empty(len(todo), JITTER_PARTIALS, dtype=torch.int64, device=dev)
+    jobs = np.zeros(len(todo), JITTER_JOB)
+    t = np.array(todo, dtype=np.uint64)
+    jobs["src"] = src_u8.data_ptr() + t * np.uint64(3 * h * w)
+    jobs["dst_f32"] = out.data_ptr() + t * np.uint64(12 * h * w)
+    jobs["lsum"] = lsum.data_ptr() + np.arange(len(todo), dtype=np.uint64) * np.uint64(8 * JITTER_PARTIALS)
+    jobs["h"], jobs["w"] = h, w
     for i, n in enumerate(todo):
         order, b, c, s, hue = params[n]
-        j = jobs[i]
-        j.src, j.dst_f32, j.dst_u8, j.lsum = src_u8[n].data_ptr(), out[n].data_ptr(), None, lsum[i].data_ptr()
-        j.h, j.w, j.hue_shift = h, w, int(hue)
-        for k in range(4):
-            j.order[k] = int(order[k]) if k < len(order) else 4
-        j.brightness, j.contrast, j.saturation = float(b), float(c), float(s)
-    _lib.check(_lib.lib().mdx_color_jitter_u8(jobs, len(todo), _lib.stream()), "mdx_color_jitter_u8")
+        jobs["order"][i] = [int(order[k]) if k < len(order) else 4 for k in range(4)]
+        jobs["hue_shift"][i], jobs["brightness"][i], jobs["contrast"][i], jobs["saturation"][i] = int(hue), b, c, s
+    if not out.is_contiguous() or out.shape != (N, 3, h, w) or out.dtype != torch.float32:
+        raise _lib.MdxError("color_jitter: out must be a contiguous float32 [N,3,h,w] tensor")
+    _lib.check(_lib.lib().mdx_color_jitter_u8(jobs.ctypes.data_as(C.c_void_p), len(todo), _lib.stream()),
+               "mdx_color_jitter_u8")
     lsum.record_stream(torch.cuda.current_stream(dev))
     return out
 
@@ -163,20 +187,29 @@ class image_prep(object):
         any_jitter = any(p is not None for p in params)
         out = {k: v for k, v in batch.items()
                if not (isinstance(k, tuple) and k[0] == "raw") and k not in ("raw_size", "raw_flip", "raw_jitter")}
+        sources = []
         for f in self.frame_ids:
             raw = batch[("raw", f)]
-            if not raw.is_cuda:
-                raw = raw.to(self.device, non_blocking=True)
-            u8, f32 = resize_lanczos(self.plans, raw, sizes, flips, (self.h, self.w), want_u8=any_jitter)
-            out[("color", f, 0)] = f32
-            if any_jitter:
-                aug = f32.clone()
-                color_jitter(u8, params, aug)
-                out[("color_aug", f, 0)] = aug
-            else:
-                out[("color_aug", f, 0)] = f32       # the reference's identity branch: the same numbers (kitti_mono.py:357-366)
-            if f == 0:
-                for s in range(1, self.scales):
-                    out[("color", 0, s)] = resize_lanczos(self.plans, raw, sizes, flips, (self.h >> s, self.w >> s))[1]
+            sources.append(raw if raw.is_cuda else raw.to(self.device, non_blocking=True))
+        # every frame at scale 0 (uint8 too when some sample is jittered), the target frame at scales 1..: one call
+        outs = [(i, (self.h, self.w), any_jitter, True) for i in range(len(sources))]
+        target = self.frame_ids.index(0)
+        outs += [(target, (self.h >> s, self.w >> s), False, True) for s in range(1, self.scales)]
+        res = resize_lanczos_multi(self.plans, sources, sizes, flips, outs)
+        B = len(sizes)
+        for i, f in enumerate(self.frame_ids):
+            out[("color", f, 0)] = res[i][1]
+            # without augmentation the reference hands the same numbers to both entries (kitti_mono.py:357-366)
+            out[("color_aug", f, 0)] = res[i][1]
+        for s in range(1, self.scales):
+            out[("color", 0, s)] = res[len(sources) + s - 1][1]
+        if any_jitter:
+            # all frames' jitter in one call; samples without a draw run the empty chain (= u8 / 255, the same numbers)
+            u8 = torch.cat([res[i][0] for i in range(len(sources))])
+            chain = [p if p is not None else ([4, 4, 4, 4], 1.0, 1.0, 1.0, 0) for p in params] * len(sources)
+            aug = color_jitter(u8, chain)
+            for i, f in enumerate(self.frame_ids):
+                out[("color_aug", f, 0)] = aug[i * B:(i + 1) * B]
+        for raw in sources:
             raw.record_stream(torch.cuda.current_stream(raw.device))
         return out

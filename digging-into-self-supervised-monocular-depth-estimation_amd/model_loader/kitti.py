@@ -58,9 +58,34 @@ class ColorJitter(object):
         return img
 
 
+def jitter_row(jitter):
+    """a ColorJitter draw as the nine numbers mdx.imgproc.image_prep reads: (enabled, order[4], b, c, s, hue_shift)."""
+    if jitter is None:
+        return [0.0] * 9
+    return [1.0] + [float(v) for v in jitter.order] + [jitter.b, jitter.c, jitter.s, float(int(jitter.h * 255))]
+
+
+def collate_raw(samples, keep=None):
+    """default_collate, with the decoded frames ("raw", f) [h,w,3] of different sizes (KITTI raw has five) padded into one
+    [B, hmax, wmax, 3] block per frame; `keep(key)` filters the other entries (processor.step_reads)."""
+    from torch.utils.data import default_collate
+    raw_keys = [k for k in samples[0] if isinstance(k, tuple) and k[0] == "raw"]
+    rest = default_collate([{k: v for k, v in s.items() if k not in raw_keys and (keep is None or keep(k))}
+                            for s in samples])
+    if raw_keys:
+        hmax = max(int(s[raw_keys[0]].shape[0]) for s in samples)
+        wmax = max(int(s[raw_keys[0]].shape[1]) for s in samples)
+        for k in raw_keys:
+            block = torch.zeros(len(samples), hmax, wmax, 3, dtype=torch.uint8)
+            for n, s in enumerate(samples):
+                block[n, : s[k].shape[0], : s[k].shape[1]] = s[k]
+            rest[k] = block
+    return rest
+
+
 class KITTIDataset(Dataset):
     def __init__(self, datapath, filename, is_training, frame_ids, height=192, width=640, ext=".jpg", scale=4,
-                 k_mode="reference_mono", gt_size=(375, 1242), load_depth=True, uint8=False):
+                 k_mode="reference_mono", gt_size=(375, 1242), load_depth=True, uint8=False, gpu_prep=False):
         if height % 32 != 0 or width % 32 != 0:
             raise ValueError("(H, W) must be multiples of 32; KITTI sizes are (192, 640) or (320, 1024)")
         self.datapath, self.filename, self.is_training = datapath, list(filename), is_training
@@ -68,6 +93,9 @@ class KITTIDataset(Dataset):
         self.ext = ext if ext.startswith(".") else "." + ext
         self.scale, self.k_mode, self.gt_size, self.load_depth = scale, k_mode, gt_size, load_depth
         self.uint8 = uint8
+        # gpu_prep: the worker only decodes; flip, the Lanczos pyramid, the jitter and ToTensor run on the GPU
+        # (mdx.imgproc.image_prep, bit-equal to the Pillow calls below)
+        self.gpu_prep = gpu_prep
 
     def __len__(self):
         return len(self.filename)
@@ -110,13 +138,24 @@ class KITTIDataset(Dataset):
         out = {}
         for frame_id in self.frame_ids:
             if frame_id == "s":
-                image = self.load_image(folder, key_frame, other, do_flip)
+                image = self.load_image(folder, key_frame, other, do_flip and not self.gpu_prep)
             else:
-                image = self.load_image(folder, key_frame + frame_id, side, do_flip)
+                image = self.load_image(folder, key_frame + frame_id, side, do_flip and not self.gpu_prep)
+            if self.gpu_prep:
+                out[("raw", frame_id)] = torch.from_numpy(np.array(image, dtype=np.uint8))      # [h, w, 3]
+                continue
             for s in range(self.scale):
                 small = image.resize((self.width // (2 ** s), self.height // (2 ** s)), Image.LANCZOS)
                 out[("color", frame_id, s)] = to_tensor(small, self.uint8)
                 out[("color_aug", frame_id, s)] = to_tensor(jitter(small), self.uint8)
+        if self.gpu_prep:
+            shapes = {tuple(out[("raw", f)].shape) for f in self.frame_ids}
+            if len(shapes) != 1:
+                raise ValueError("frames of one sample differ in size: %s" % sorted(shapes))
+            h, w, _ = shapes.pop()
+            out["raw_size"] = torch.tensor([h, w], dtype=torch.int32)
+            out["raw_flip"] = torch.tensor(bool(do_flip))
+            out["raw_jitter"] = torch.tensor(jitter_row(jitter if do_color else None), dtype=torch.float64)
         if self.load_depth:
             out[("depth", 0)] = self.load_point(folder, key_frame, side, do_flip)
         for s in range(self.scale):

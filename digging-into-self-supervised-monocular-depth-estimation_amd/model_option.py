@@ -44,6 +44,11 @@ def options(argv=None):
                    help="single-GPU training: capture the step into one hipGraph and replay it (host launch cost off the critical path)")
     p.add_argument("--device_prefetch", type=lambda s: str(s).lower() in ("1", "true", "yes"), default=True,
                    help="upload the next batch on a side stream while the current step computes")
+    p.add_argument("--gpu_image_prep", type=str, default="auto", choices=["auto", "true", "false"],
+                   help="KITTI loaders: workers only decode; flip, Lanczos pyramid, colour jitter and ToTensor run on the GPU "
+                        "(bit-equal to Pillow; csrc/imgproc.hip).  auto = on when training on a GPU")
+    p.add_argument("--synthetic_raw", action="store_true",
+                   help="synthetic dataset hands over KITTI-sized decoded frames (1242x375 uint8), as the KITTI loaders do with gpu_image_prep")
     p.add_argument("--synthetic_pool", type=int, default=0, help="synthetic dataset: number of distinct samples kept (0 = all)")
     p.add_argument("--noise", type=str, default="device", choices=["device", "cpu"])
     p.add_argument("--amp", type=str, default="none", choices=["none", "bf16"])

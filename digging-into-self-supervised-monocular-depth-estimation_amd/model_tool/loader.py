@@ -25,6 +25,19 @@ def collate_step_keys(samples):
     return default_collate([{k: v for k, v in s.items() if step_reads(k)} for s in samples])
 
 
+def collate_raw_step_keys(samples):
+    """gpu_image_prep: the decoded frames padded into one block per frame id (model_loader.kitti.collate_raw)."""
+    from model_loader.kitti import collate_raw
+    from .processor import step_reads
+    return collate_raw(samples, step_reads)
+
+
+def gpu_image_prep(opt, device):
+    """opt.gpu_image_prep: "auto" = on when the step runs on a GPU (the kernels have no CPU counterpart)."""
+    v = str(_opt(opt, "gpu_image_prep", "auto")).lower()
+    return str(device).startswith("cuda") if v == "auto" else v in ("1", "true", "yes")
+
+
 class setting(object):
     def __init__(self, opt, device):
         self.opt = opt
@@ -52,7 +65,9 @@ class setting(object):
             length = _opt(opt, "synthetic_length", 64 * opt.batch) if is_training else 4 * opt.batch
             dataset = SyntheticKITTI(length, opt.frame_ids, opt.height, opt.width, len(opt.scales),
                                      seed=0 if is_training else 1, pool=_opt(opt, "synthetic_pool", 0),
-                                     uint8=_opt(opt, "uint8_loader", False))
+                                     uint8=_opt(opt, "uint8_loader", False),
+                                     raw=gpu_image_prep(opt, self.device) and _opt(opt, "synthetic_raw", False),
+                                     is_training=is_training)
         else:
             from model_loader import KITTIMonoDataset_v2, KITTIMonoStereoDataset
             from model_utility import readlines
@@ -60,6 +75,7 @@ class setting(object):
             cls = KITTIMonoDataset_v2 if opt.dataset == "kitti_mono" else KITTIMonoStereoDataset
             dataset = cls(opt.datapath, names, is_training, opt.frame_ids, opt.height, opt.width, ".jpg", len(opt.scales))
             dataset.uint8 = _opt(opt, "uint8_loader", False)
+            dataset.gpu_prep = gpu_image_prep(opt, self.device)
         sampler = None
         if self.distributed:
             sampler = DistributedSampler(dataset, self.world_size, self.rank, shuffle=shuffle, drop_last=True)
@@ -67,7 +83,8 @@ class setting(object):
         workers = opt.num_workers
         return DataLoader(dataset, opt.batch, shuffle, sampler=sampler, num_workers=workers,
                           drop_last=True, pin_memory=str(self.device).startswith("cuda"),
-                          collate_fn=collate_step_keys if _opt(opt, "collate_step_keys", False) else None,
+                          collate_fn=(collate_raw_step_keys if getattr(dataset, "gpu_prep", False) or getattr(dataset, "raw", False)
+                                      else collate_step_keys if _opt(opt, "collate_step_keys", False) else None),
                           persistent_workers=workers > 0, prefetch_factor=(_opt(opt, "prefetch_factor", 4) if workers > 0 else None))
 
     # reference: loader.py:70-96

@@ -38,6 +38,13 @@ def step_reads(key):
     return True                                             # ("depth", 0), injected test entries
 
 
+HOST_KEYS = ("raw_size", "raw_flip", "raw_jitter")     # read on the host by mdx.imgproc.image_prep: never uploaded
+
+
+def device_key(key):
+    return step_reads(key) and key not in HOST_KEYS
+
+
 class compute(object):
     def __init__(self, opt, device):
         self.opt = opt
@@ -51,6 +58,7 @@ class compute(object):
         self.amp = _opt(opt, "amp", "none")
         # both frame pairs through the separate pose network in one batch (same numbers, see below)
         self.batch_pose_pairs = _opt(opt, "batch_pose_pairs", True)
+        self._prep = None
 
     # -- networks ---------------------------------------------------------------------------------
     def _autocast(self):
@@ -58,10 +66,21 @@ class compute(object):
         return torch.autocast(device_type="cuda", dtype=torch.bfloat16, enabled=enabled)
 
     def _step_reads(self, key):
-        return step_reads(key)
+        return device_key(key)
+
+    def prepare(self, inputs):
+        """Batches that carry decoded frames (("raw", f), model_loader.kitti with gpu_prep): flip, Lanczos pyramid, colour
+        jitter and ToTensor on the GPU, on the current stream -> the entries the step reads.  Other batches pass."""
+        from mdx.imgproc import image_prep
+        if not image_prep.wanted(inputs):
+            return inputs
+        if self._prep is None:
+            self._prep = image_prep(self.opt.height, self.opt.width, self.opt.frame_ids, len(self.opt.scales), self.device)
+        return self._prep(inputs)
 
     def forward_depth(self, inputs, outputs, setting):
         dev = torch.device(self.device)
+        inputs = self.prepare(inputs)
         for key in inputs:
             if torch.is_tensor(inputs[key]) and inputs[key].device != dev and self._step_reads(key):
                 inputs[key] = inputs[key].to(self.device, non_blocking=True)

@@ -15,7 +15,8 @@ def make_K(height, width):
 
 
 class SyntheticKITTI(Dataset):
-    def __init__(self, length, frame_ids, height, width, num_scales=4, seed=0, gt_size=(375, 1242), pool=0, uint8=False):
+    def __init__(self, length, frame_ids, height, width, num_scales=4, seed=0, gt_size=(375, 1242), pool=0, uint8=False,
+                 raw=False, is_training=True):
         """pool > 0: only `pool` distinct samples are ever generated (index modulo pool) and they are kept -- the
         generator below costs ~20 ms per sample, far more than decoding a KITTI frame; a throughput measurement of the
         training LOOP must not be a measurement of this stand-in."""
@@ -23,6 +24,9 @@ class SyntheticKITTI(Dataset):
         self.height, self.width, self.num_scales = height, width, num_scales
         self.seed, self.gt_size, self.pool, self._cache = seed, gt_size, pool, {}
         self.uint8 = uint8                    # colours as uint8 (x 255), as model_loader.kitti with uint8=True
+        # raw: decoded frames of KITTI's size ([375,1242,3] uint8) + flip / jitter draws, as model_loader.kitti with
+        # gpu_prep=True hands them over; mdx.imgproc.image_prep builds the step's entries on the GPU
+        self.raw, self.is_training = raw, is_training
 
     def __len__(self):
         return self.length
@@ -41,7 +45,23 @@ class SyntheticKITTI(Dataset):
         base = torch.rand(3, self.height // 8, self.width // 8, generator=g)
         base = torch.nn.functional.interpolate(base[None], size=(self.height, self.width), mode="bilinear",
                                                align_corners=False)[0]
+        if self.raw:
+            import random as _random
+            from model_loader.kitti import ColorJitter, jitter_row
+            gh, gw = self.gt_size
+            big = torch.nn.functional.interpolate(base[None], size=(gh, gw), mode="bilinear", align_corners=False)[0]
+            for k, f in enumerate(self.frame_ids):
+                img = torch.roll(big, shifts=0 if f == 0 else 6 * k, dims=2) + 0.05 * torch.rand(3, gh, gw, generator=g)
+                inputs[("raw", f)] = (img.clamp(0, 1) * 255).round().to(torch.uint8).permute(1, 2, 0).contiguous()
+            r = _random.Random(self.seed * 7919 + index)
+            do_color = self.is_training and r.random() > 0.5
+            do_flip = self.is_training and r.random() > 0.5
+            inputs["raw_size"] = torch.tensor([gh, gw], dtype=torch.int32)
+            inputs["raw_flip"] = torch.tensor(bool(do_flip))
+            inputs["raw_jitter"] = torch.tensor(jitter_row(ColorJitter(r) if do_color else None), dtype=torch.float64)
         for k, f in enumerate(self.frame_ids):
+            if self.raw:
+                break
             shift = 0 if f == 0 else (3 * k)
             img = torch.roll(base, shifts=shift, dims=2) + 0.05 * torch.rand(3, self.height, self.width, generator=g)
             img = img.clamp(0, 1)

@@ -20,16 +20,18 @@ class device_prefetcher(object):
     (~0.13 GB per batch of 12 at 192x640) is off the critical path.  The reference copies every key at the start of
     each step on the compute stream (processor.py:34-35)."""
 
-    def __init__(self, loader, device, wanted):
-        self.loader, self.device, self.wanted = loader, device, wanted
+    def __init__(self, loader, device, wanted, prepare=None):
+        self.loader, self.device, self.wanted, self.prepare = loader, device, wanted, prepare
         self.stream = torch.cuda.Stream(device) if str(device).startswith("cuda") else None
 
     def _upload(self, batch):
         if self.stream is None or batch is None:
             return batch
         with torch.cuda.stream(self.stream):
-            return {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) and self.wanted(k) else v)
-                    for k, v in batch.items()}
+            batch = {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) and self.wanted(k) else v)
+                     for k, v in batch.items()}
+            # decoded frames -> the step's entries (compute.prepare), also on the side stream
+            return self.prepare(batch) if self.prepare is not None else batch
 
     def __iter__(self):
         it = iter(self.loader)
@@ -117,7 +119,7 @@ class trainer(object):
     def batches(self, loader):
         """The loader's batches, uploaded one step ahead on a side stream (GPU) or as they are (CPU)."""
         if str(self.device).startswith("cuda") and getattr(self.opt, "device_prefetch", True):
-            return device_prefetcher(loader, self.device, self.compute._step_reads)
+            return device_prefetcher(loader, self.device, self.compute._step_reads, self.compute.prepare)
         return loader
 
     def batch_process(self, inputs):
@@ -142,6 +144,7 @@ class trainer(object):
                      and not self.setting.distributed)
         if not use_graph:
             return self._eager_step(inputs)
+        inputs = self.compute.prepare(inputs)     # decoded frames -> step entries (a no-op after the prefetcher)
         if self._graphed is None:
             self._graphed = graphed_step(self, inputs)
         mon = getattr(self.control, "_side", None)

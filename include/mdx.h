@@ -306,11 +306,13 @@ int mdx_depth_monitor(const float *pred, int B, int h, int w, const float *gt, i
  * Jobs are HOST arrays of plain structs whose pointers are DEVICE pointers (except where noted); they are passed to the
  * kernels by value, MDX_IMG_JOBS per launch, so the caller may free or reuse the array on return. */
 #define MDX_IMG_JOBS 32
+#define MDX_JITTER_PARTIALS 128
 
 /* taps per output sample of the Lanczos-3 plan in_size -> out_size (2*ceil(3*max(in/out,1)) + 1) */
 int mdx_resample_ksize(int in_size, int out_size);
 /* Resample.c precompute_coeffs + normalize_coeffs_8bpc: bounds [out_size][2] = (first source sample, number of taps),
- * kk [out_size][ksize] = 22-bit fixed-point weights.  HOST arrays (the caller uploads and caches them per size pair). */
+ * kk [ksize][out_size] = 22-bit fixed-point weights, TAP-MAJOR (the transpose of Pillow's table, so that consecutive
+ * outputs read consecutive weights).  HOST arrays (the caller uploads and caches them per size pair). */
 int mdx_resample_plan(int in_size, int out_size, int *bounds, int *kk);
 
 typedef struct mdx_resample_job {
@@ -330,7 +332,7 @@ typedef struct mdx_jitter_job {
     const uint8_t *src;          /* planar [3][h][w] */
     float *dst_f32;              /* planar [3][h][w] = u8 / 255, or NULL */
     uint8_t *dst_u8;             /* planar, or NULL (may alias src: each pixel is read before it is written) */
-    unsigned long long *lsum;    /* scratch, one 8-byte word per job (sum of L for Contrast) */
+    unsigned long long *lsum;    /* scratch, MDX_JITTER_PARTIALS 8-byte words per job (partial sums of L for Contrast) */
     int h, w;
     int order[4];                /* 0 brightness, 1 contrast, 2 saturation, 3 hue, 4 = empty slot; each at most once */
     int hue_shift;               /* int(hue_factor * 255), added to the H byte modulo 256 */

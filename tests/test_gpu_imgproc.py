@@ -57,6 +57,7 @@ def _pil_resize(img, oh, ow, flip):
     dict(sizes=[(20, 30), (17, 30)], out=(40, 60)),                                        # upscale
     dict(sizes=[(48, 64)], out=(48, 64)),                                                  # identity plan
     dict(sizes=[(50, 50)], out=(50, 25)),
+    dict(sizes=[(5, 2), (4, 3), (1, 2)], out=(3, 2)),                                      # narrowest sources, odd rows
     dict(sizes=[(33, 47)] * 37, out=(16, 24)),                                             # > MDX_IMG_JOBS jobs
 ])
 def test_resize_lanczos_bit_exact(G, IP, case):
@@ -72,6 +73,14 @@ def test_resize_lanczos_bit_exact(G, IP, case):
         assert np.array_equal(ref, _pil_resize(img, oh, ow, flips[n]))                      # oracle == Pillow
         assert np.array_equal(u8[n], ref.transpose(2, 0, 1)), "image %d" % n
         assert np.array_equal(f32[n].view(np.uint32), orc.to_tensor(ref).view(np.uint32)), "ToTensor %d" % n
+
+
+def test_resize_wide_source(G, IP):
+    """a source 350x wider than its output (2101 taps per column)."""
+    rng = np.random.default_rng(77)
+    img = _natural(rng, 9, 14000)
+    got = IP.resize_lanczos(IP.plan_cache("cuda:0"), torch.from_numpy(img[None]).cuda(), [(9, 14000)], [True], (5, 40), want_u8=True)[0]
+    assert np.array_equal(got[0].cpu().numpy(), orc.resample_lanczos(img, 5, 40, True).transpose(2, 0, 1))
 
 
 def test_color_maps_exhaustive(G, IP):
@@ -158,3 +167,33 @@ def test_imgproc_refuses_bad_input(G, IP):
         IP.resize_lanczos(plans, torch.zeros(1, 8, 8, 3, dtype=torch.uint8).cuda(), [(9, 8)], [False], (4, 4))
     with pytest.raises(MdxError):
         IP.color_jitter(torch.zeros(1, 3, 8, 8, dtype=torch.uint8).cuda(), [([0, 0, 1, 2], 1.0, 1.0, 1.0, 0)])
+
+
+def test_kitti_loader_gpu_prep_equals_pillow_path(G, IP, tmp_path):
+    """End to end on a JPEG tree: KITTIDataset(gpu_prep) -> padded collate -> image_prep  ==  the Pillow loader's
+    entries for the same random draws (flip and jitter included), every entry a step reads."""
+    import fake_kitti
+    from model_loader import KITTIMonoStereoDataset
+    from model_loader.kitti import collate_raw
+    from model_tool.processor import step_reads
+    names = fake_kitti.make(str(tmp_path), n_frames=6)
+    frames = [0, -1, 1, "s"]
+    cpu = KITTIMonoStereoDataset(str(tmp_path), names, True, frames, 192, 640, "jpg", 4)
+    raw = KITTIMonoStereoDataset(str(tmp_path), names, True, frames, 192, 640, "jpg", 4)
+    raw.gpu_prep = True
+    ref, samples = [], []
+    for i in range(len(names)):
+        random.seed(40 + i)
+        ref.append(cpu[i])
+        random.seed(40 + i)
+        samples.append(raw[i])
+    assert any(bool(s["raw_flip"]) for s in samples) and any(bool(s["raw_jitter"][0]) for s in samples)
+    out = IP.image_prep(192, 640, frames, 4, "cuda:0")(collate_raw(samples, step_reads))
+    for key, value in out.items():
+        if isinstance(key, tuple) and key[0] in ("color", "color_aug"):
+            for b in range(len(names)):
+                assert torch.equal(value[b].cpu(), ref[b][key]), (key, b)
+    for b in range(len(names)):
+        assert torch.equal(out["stereo"][b], ref[b]["stereo"])
+    wanted = {k for k in ref[0] if step_reads(k)}
+    assert wanted == set(out.keys()), wanted ^ set(out.keys())

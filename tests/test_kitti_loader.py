@@ -63,3 +63,41 @@ def test_point2depth_projection(tmp_path):
     assert mu.resize_nearest(full, (100, 300)).shape == (100, 300)
     Kl, Kr = mu.read_cam2cam(os.path.join(calib, "calib_cam_to_cam.txt"))
     assert Kl.shape == (4, 4) and abs(Kl[0, 0] - 721.5377) < 1e-3 and Kr[3, 3] == 1
+
+
+def test_gpu_prep_mode_hands_over_decoded_frames(tmp_path):
+    """gpu_prep=True: the worker decodes only; same random draws as the Pillow path; padded collate."""
+    import random
+    from PIL import Image
+    from model_loader.kitti import collate_raw
+    from model_tool.processor import step_reads, device_key
+    names = fake_kitti.make(str(tmp_path))
+    cpu = KITTIMonoDataset_v2(str(tmp_path), names, True, [0, -1, 1], 192, 640, "jpg", 4)
+    raw = KITTIMonoDataset_v2(str(tmp_path), names, True, [0, -1, 1], 192, 640, "jpg", 4)
+    raw.gpu_prep = True
+    for i in range(len(names)):
+        random.seed(100 + i)
+        a = cpu[i]
+        random.seed(100 + i)
+        b = raw[i]
+        assert not any(isinstance(k, tuple) and k[0] in ("color", "color_aug") for k in b)
+        assert b[("raw", 0)].shape == (375, 1242, 3) and b[("raw", 0)].dtype == torch.uint8
+        assert b["raw_size"].tolist() == [375, 1242]
+        assert torch.equal(a[("depth", 0)], b[("depth", 0)]) and torch.equal(a[("K", 0)], b[("K", 0)])
+        # the frame is handed over unflipped and undistorted by augmentation: Pillow on it reproduces the CPU entry
+        im = Image.fromarray(b[("raw", -1)].numpy())
+        if bool(b["raw_flip"]):
+            im = im.transpose(Image.FLIP_LEFT_RIGHT)
+        from model_loader.kitti import to_tensor
+        assert torch.equal(to_tensor(im.resize((640, 192), Image.LANCZOS)), a[("color", -1, 0)])
+        jittered = not torch.equal(a[("color", 0, 0)], a[("color_aug", 0, 0)])
+        assert bool(b["raw_jitter"][0]) == jittered or not jittered
+    small = dict(raw[0])
+    for f in (0, -1, 1):
+        small[("raw", f)] = small[("raw", f)][:370, :1226].contiguous()
+    small["raw_size"] = torch.tensor([370, 1226], dtype=torch.int32)
+    batch = collate_raw([raw[1], small], step_reads)
+    assert batch[("raw", 1)].shape == (2, 375, 1242, 3) and batch["raw_size"].tolist() == [[375, 1242], [370, 1226]]
+    assert (batch[("raw", 1)][1, 370:] == 0).all() and (batch[("raw", 1)][1, :, 1226:] == 0).all()
+    assert ("K", 1) not in batch and batch["raw_jitter"].shape == (2, 9)
+    assert step_reads("raw_size") and not device_key("raw_size") and device_key(("raw", 0))

@@ -8,13 +8,16 @@ import os
 import sys
 
 
+FILTER = os.environ.get("MDX_PMC_FILTER", "mdx::photometric,mdx::train_finish").split(",")
+
+
 def main():
     dst, dirs = sys.argv[1], sys.argv[2:]
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for d in dirs:
         for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
-                if "mdx::photometric" in r["Kernel_Name"] or "mdx::train_finish" in r["Kernel_Name"]:
+                if any(f in r["Kernel_Name"] for f in FILTER):
                     agg[r["Kernel_Name"].replace("void ", "")[:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     lines = ["# rocprofv3 --pmc, mean per launch (tools/kbench.py: B=12, 192x640, S=2, all four scales)"]
     for k in sorted(agg):
