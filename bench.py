@@ -220,7 +220,7 @@ def selftest_launcher(gpus):
     return 0 if int(ones[0]) == gpus else 3
 
 
-def trainer_loop(args, frame_ids, steps, warmup, workers):
+def trainer_loop(args, frame_ids, steps, warmup, workers, raw):
     """The loop people run (model_train.trainer): batches from the DataLoader (worker processes, pinned memory, uploaded
     one step ahead on a side stream), train_step, and control.metric on every step -- beside the resident-input figure."""
     from model_train import trainer
@@ -233,7 +233,9 @@ def trainer_loop(args, frame_ids, steps, warmup, workers):
     opt.collate_step_keys = not args.float_loader
     opt.graph = not args.trainer_eager
     # decoded KITTI-sized frames through the loader; flip / Lanczos pyramid / jitter / ToTensor on the GPU (csrc/imgproc.hip)
-    opt.synthetic_raw, opt.gpu_image_prep = bool(args.raw_frames), "true" if args.raw_frames else "false"
+    opt.synthetic_raw, opt.gpu_image_prep = raw, "true" if raw else "false"
+    if raw:
+        opt.synthetic_pool = 2 * args.batch      # a decoded frame is 1.4 MB: keep the workers' pools small
     opt.max_steps, opt.miopen_find = 0, args.miopen_find
     if os.environ.get("MDX_SWITCH_INTERVAL"):
         sys.setswitchinterval(float(os.environ["MDX_SWITCH_INTERVAL"]))
@@ -252,11 +254,17 @@ def trainer_loop(args, frame_ids, steps, warmup, workers):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     vals = {k: tr.control._mean(v) for k, v in log.items()}
-    del it
+    del it, b
+    # the persistent loader workers and the captured graph of this trainer must not outlive the measurement
+    import gc
+    tr._graphed = None
+    tr.setting.train_dataloader = tr.setting.valid_dataloader = None
+    del tr
+    gc.collect()
+    torch.cuda.synchronize()
     return {"value": args.batch * steps / dt, "unit": "images/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
             "workers": workers, "uint8_loader": bool(opt.uint8_loader), "hip_graph": bool(opt.graph),
-            "raw_frames": bool(args.raw_frames), "what": "model_train.trainer: DataLoader (pinned, side-stream upload) -> train_step -> "
-                                        "control.metric every step", "abs_rel_monitor": vals.get("abs_rel")}
+            "raw_frames": raw, "what": "model_train.trainer: DataLoader (" + ("decoded 1242x375 frames, Lanczos pyramid / jitter / ToTensor on the GPU, " if raw else "prepared uint8 entries, ") + "pinned, side-stream upload) -> train_step -> control.metric every step", "abs_rel_monitor": vals.get("abs_rel")}
 
 
 def main():
@@ -284,9 +292,8 @@ def main():
                     help="trainer loop with the reference's float32 colours through the DataLoader (4x the host bytes)")
     ap.add_argument("--trainer-eager", action="store_true",
                     help="trainer loop without the hipGraph replay of the step (model_option --graph 0)")
-    ap.add_argument("--raw-frames", action="store_true",
-                    help="trainer loop fed with decoded 1242x375 frames (what the KITTI loaders hand over with "
-                         "--gpu_image_prep): the Lanczos pyramid, the colour jitter and ToTensor run on the GPU")
+    ap.add_argument("--one-loop", action="store_true",
+                    help="trainer loop only with decoded frames (skip the second run fed with ready 192x640 entries)")
     ap.add_argument("--workers", type=int, default=12, help="DataLoader workers of the trainer-loop measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -473,8 +480,20 @@ def main():
         if not args.no_trainer_loop and world == 1 and graph is None:
             del st, cp, inputs, optim
             torch.cuda.empty_cache()
-            line["trainer_loop"] = trainer_loop(args, frame_ids, args.steps, args.warmup, args.workers)
+            # twice: fed with decoded 1242x375 frames (the data path of a real run: pyramid / jitter / ToTensor are
+            # extra GPU work the resident figure does not contain) and with ready entries (the loop alone)
+            line["trainer_loop"] = trainer_loop(args, frame_ids, args.steps, args.warmup, args.workers, True)
             line["trainer_loop"]["vs_resident"] = line["trainer_loop"]["value"] / line["value"]
+            if not args.one_loop:
+                torch.cuda.empty_cache()
+                line["trainer_loop_prepared_frames"] = trainer_loop(args, frame_ids, args.steps, args.warmup, args.workers, False)
+                line["trainer_loop_prepared_frames"]["vs_resident"] = line["trainer_loop_prepared_frames"]["value"] / line["value"]
+            # the data layer's share: host cost per sample with and without the GPU image preparation
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import loader_cost
+            line["image_prep"] = loader_cost.measure(samples=12, batch=args.batch, reps=10, height=args.height,
+                                                     width=args.width, frames=[f for f in frame_ids])
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))

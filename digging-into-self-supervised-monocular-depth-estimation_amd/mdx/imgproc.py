@@ -66,7 +66,8 @@ def resize_lanczos_multi(plans, sources, sizes, flips, outs):
     """Image.resize((out_w, out_h), Image.LANCZOS) for several blocks of images and several output sizes in ONE call.
     sources: list of uint8 [N, hmax, wmax, 3] (image n occupies [:h_n, :w_n]); sizes [(h, w)] * N and flips [bool] * N
     hold for every block (the frames of a sample share them).  outs: list of (block index, (out_h, out_w), want_u8,
-    want_f32) -> list of (uint8 [N,3,out_h,out_w] or None, float32 [N,3,out_h,out_w] = u8 / 255 or None)."""
+    want_f32) -> list of (uint8 [N,3,out_h,out_w] or None, float32 [N,3,out_h,out_w] = u8 / 255 or None); want_u8 may
+    be a uint8 [N,3,out_h,out_w] tensor to write into (e.g. a slice of a larger block)."""
     N = len(sizes)
     for src in sources:
         _check_u8(src, "src")
@@ -89,7 +90,13 @@ def resize_lanczos_multi(plans, sources, sizes, flips, outs):
         oh, ow = int(oh), int(ow)
         if hs.min() <= 0 or ws.min() <= 0 or hs.max() > hmax or ws.max() > wmax:
             raise _lib.MdxError("resize_lanczos: an image of %s does not fit its %dx%d slot" % (sizes, hmax, wmax))
-        u8 = torch.empty(N, 3, oh, ow, dtype=torch.uint8, device=dev) if want_u8 else None
+        if torch.is_tensor(want_u8):
+            u8, want_u8 = want_u8, True
+            _check_u8(u8, "want_u8")
+            if tuple(u8.shape) != (N, 3, oh, ow):
+                raise _lib.MdxError("resize_lanczos: the uint8 output must be [N,3,%d,%d]" % (oh, ow))
+        else:
+            u8 = torch.empty(N, 3, oh, ow, dtype=torch.uint8, device=dev) if want_u8 else None
         f32 = torch.empty(N, 3, oh, ow, dtype=torch.float32, device=dev) if want_f32 else None
         results.append((u8, f32))
         j = jobs[o * N:(o + 1) * N]
@@ -192,11 +199,12 @@ class image_prep(object):
             raw = batch[("raw", f)]
             sources.append(raw if raw.is_cuda else raw.to(self.device, non_blocking=True))
         # every frame at scale 0 (uint8 too when some sample is jittered), the target frame at scales 1..: one call
-        outs = [(i, (self.h, self.w), any_jitter, True) for i in range(len(sources))]
+        B, F = len(sizes), len(sources)
+        u8 = torch.empty(F * B, 3, self.h, self.w, dtype=torch.uint8, device=sources[0].device) if any_jitter else None
+        outs = [(i, (self.h, self.w), u8[i * B:(i + 1) * B] if any_jitter else False, True) for i in range(F)]
         target = self.frame_ids.index(0)
         outs += [(target, (self.h >> s, self.w >> s), False, True) for s in range(1, self.scales)]
         res = resize_lanczos_multi(self.plans, sources, sizes, flips, outs)
-        B = len(sizes)
         for i, f in enumerate(self.frame_ids):
             out[("color", f, 0)] = res[i][1]
             # without augmentation the reference hands the same numbers to both entries (kitti_mono.py:357-366)
@@ -205,7 +213,6 @@ class image_prep(object):
             out[("color", 0, s)] = res[len(sources) + s - 1][1]
         if any_jitter:
             # all frames' jitter in one call; samples without a draw run the empty chain (= u8 / 255, the same numbers)
-            u8 = torch.cat([res[i][0] for i in range(len(sources))])
             chain = [p if p is not None else ([4, 4, 4, 4], 1.0, 1.0, 1.0, 0) for p in params] * len(sources)
             aug = color_jitter(u8, chain)
             for i, f in enumerate(self.frame_ids):
