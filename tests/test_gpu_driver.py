@@ -214,3 +214,55 @@ def test_trainer_graph_replay_matches_eager(G):
     o1 = float(tr._eager_step(dict(tr._graphed.static))["loss"].detach())
     o2 = float(tr._graphed(dict(tr._graphed.static))["loss"].detach())
     assert np.isfinite(o1) and np.isfinite(o2) and abs(o1 - o2) < 0.05 * abs(o1)
+
+
+def test_trainer_on_kitti_tree_gpu_image_prep_equals_pillow_loader(G, tmp_path):
+    """model_train.trainer on a KITTI-raw tree (JPEG frames): with gpu_image_prep the workers hand over decoded frames
+    and csrc/imgproc.hip builds the step's entries -- the SAME entries, so the first training step gives the SAME loss
+    as with the Pillow loader (same random draws; auto-masking off: its noise is drawn on the device).  Then the loop
+    people run: prefetcher + graph replay + validation, with worker processes."""
+    import importlib
+    import os
+    import random
+    import fake_kitti
+    from model_train import trainer
+    bench = importlib.import_module("bench")
+    names = fake_kitti.make(str(tmp_path), n_frames=10)
+    os.makedirs(os.path.join(str(tmp_path), "splits", "fake"))
+    for split in ("train", "val", "test"):
+        open(os.path.join(str(tmp_path), "splits", "fake", split + "_files.txt"), "w").write("\n".join(names) + "\n")
+
+    def make(prep, graph, workers):
+        opt = bench.make_opt(2, height=192, width=640, workers=workers)
+        opt.dataset, opt.datapath, opt.datatype = "kitti_mono", str(tmp_path), "fake"
+        opt.splits = os.path.join(str(tmp_path), "splits")
+        opt.use_automasking, opt.graph, opt.max_steps, opt.miopen_find = False, graph, 3, False
+        opt.gpu_image_prep, opt.uint8_loader, opt.collate_step_keys = prep, True, True
+        return opt
+
+    losses = {}
+    for prep in ("true", "false"):
+        torch.manual_seed(0)
+        random.seed(0)
+        tr = trainer(make(prep, False, 0))
+        tr.setting.set_train()
+        assert bool(getattr(tr.setting.train_dataloader.dataset, "gpu_prep", False)) == (prep == "true")
+        out = []
+        for step, b in enumerate(tr.batches(tr.setting.train_dataloader)):
+            if prep == "true":
+                assert ("color", 0, 0) in b and b[("color", 0, 0)].is_cuda and ("raw", 0) not in b    # prepared by the prefetcher
+            out.append(float(tr.train_step(b)["loss"].detach()))
+            if step == 2:
+                break
+        losses[prep] = out
+    # identical entries -> the first loss is the same float; later steps inherit the convolutions' run-to-run
+    # float32 summation noise through the weights
+    assert losses["true"][0] == losses["false"][0], losses
+    assert np.allclose(losses["true"], losses["false"], rtol=1e-4), losses
+    # the full loop: worker processes, side-stream upload + preparation, hipGraph replay, validation, checkpoint
+    torch.manual_seed(0)
+    opt = make("true", True, 2)
+    opt.save = os.path.join(str(tmp_path), "ckpt")
+    tr = trainer(opt)
+    tr.train()
+    assert tr._graphed is not None
