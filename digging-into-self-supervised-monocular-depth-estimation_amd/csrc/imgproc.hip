@@ -16,6 +16,7 @@
 // nothing to copy, capturable.  Layouts: source = interleaved RGB rows as Pillow / the JPEG decoder hand them over
 // ([h][w][3] uint8, row stride in bytes); everything downstream is planar ([3][h][w]), the step's layout.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include "mdx_common.hpp"
 
@@ -25,6 +26,7 @@ constexpr int RS_BITS = 32 - 8 - 2;          // Resample.c PRECISION_BITS
 
 struct ResampleJob : mdx_resample_job {
     int vec4;                 // the vertical pass may use dword accesses (alignment and row length checked on the host)
+    int h_taps;               // horizontal pass: 0 = lanes along the columns, C > 0 = resample_h_taps_kernel<C>
 };
 struct ResampleJobs {
     ResampleJob j[MDX_IMG_JOBS];
@@ -112,6 +114,7 @@ static __device__ __forceinline__ void resample_h_body(const ResampleJob &J, int
 __global__ __launch_bounds__(256) void resample_h_kernel(ResampleJobs jobs)
 {
     const ResampleJob &J = jobs.j[blockIdx.z];
+    if (J.h_taps) return;                                            // this job runs in resample_h_taps_kernel
     const int lane = threadIdx.x & 63;
     const int xo0 = blockIdx.x * 64;
     const int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * HR;
@@ -120,6 +123,63 @@ __global__ __launch_bounds__(256) void resample_h_kernel(ResampleJobs jobs)
     const int xo = min(xo0 + lane, J.out_w - 1);
     if (J.flip) resample_h_body<true>(J, xo, y0, ok, lane);
     else resample_h_body<false>(J, xo, y0, ok, lane);
+}
+
+// Horizontal pass for strong reductions (65..128 taps: the 80-column scale of a 1242-wide frame has 95).  With lanes along the
+// output columns a tap load gathers at a stride of 3*in/out bytes -- 46 bytes for the 80-column scale: 64 cache lines
+// per instruction, 6 % of each used.  Here a WAVE owns one output column: each 16-lane DPP row takes one source row,
+// each lane a contiguous chunk of C taps (16*C >= taps; the row's taps are 3*n contiguous bytes), and four row-local
+// DPP adds finish the sum -- 3 reduction instructions per output instead of 18 for a whole-wave reduction.  The
+// column's weights stay in registers while the wave walks down the rows.
+constexpr int HT_ROWS = 96;            // rows per block (4 at a time)
+template <int C>
+__global__ __launch_bounds__(256) void resample_h_taps_kernel(ResampleJobs jobs)
+{
+    const ResampleJob &J = jobs.j[blockIdx.z];
+    if (J.h_taps != C) return;
+    const int lane = threadIdx.x & 63, xo = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int y0 = blockIdx.y * HT_ROWS;
+    if (xo >= J.out_w || y0 >= J.in_h) return;                         // wave-uniform
+    const int sub = lane & 15, rr = lane >> 4;
+    const int xmin = J.xbounds[2 * xo], n = J.xbounds[2 * xo + 1];
+    const int last = J.in_w - 1;
+    int w[C], off[C], sh[C];
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        const int t = sub * C + j, tt = min(t, n - 1);                  // past the last tap: its address, weight 0
+        w[j] = t < n ? J.xkk[(size_t)t * J.out_w + xo] : 0;
+        const int px = J.flip ? last - (xmin + tt) : xmin + tt;
+        const int edge = px == last ? 1 : 0;
+        off[j] = 3 * px - edge;
+        sh[j] = 8 * edge;
+    }
+    const size_t plane = (size_t)J.in_h * J.out_w;
+    const int y1 = min(y0 + HT_ROWS, J.in_h);
+    for (int yb = y0; yb < y1; yb += 4) {                               // every lane runs every iteration (DPP below)
+        const int y = yb + rr;
+        const uint8_t *row = J.src + (size_t)min(y, J.in_h - 1) * J.in_stride;
+        int s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            const unsigned v = load32_unaligned(row + off[j]) >> sh[j];
+            s0 += __mul24((int)(v & 255u), w[j]);
+            s1 += __mul24((int)((v >> 8) & 255u), w[j]);
+            s2 += __mul24((int)((v >> 16) & 255u), w[j]);
+        }
+        // sum over the 16 lanes of the DPP row: lane 15 of each row ends with the total (row_shr, zero fill)
+#define MDX_ROW_SHR_ADD(d)                                                     \
+        s0 += __builtin_amdgcn_update_dpp(0, s0, 0x110 + d, 0xf, 0xf, true);   \
+        s1 += __builtin_amdgcn_update_dpp(0, s1, 0x110 + d, 0xf, 0xf, true);   \
+        s2 += __builtin_amdgcn_update_dpp(0, s2, 0x110 + d, 0xf, 0xf, true);
+        MDX_ROW_SHR_ADD(8) MDX_ROW_SHR_ADD(4) MDX_ROW_SHR_ADD(2) MDX_ROW_SHR_ADD(1)
+#undef MDX_ROW_SHR_ADD
+        if (sub == 15 && y < J.in_h) {
+            const size_t o = (size_t)y * J.out_w + xo;
+            J.inter[o] = clip8(s0 + (1 << (RS_BITS - 1)));
+            J.inter[plane + o] = clip8(s1 + (1 << (RS_BITS - 1)));
+            J.inter[2 * plane + o] = clip8(s2 + (1 << (RS_BITS - 1)));
+        }
+    }
 }
 
 // Vertical pass: planar inter [3][in_h][out_w] -> planar [3][out_h][out_w] uint8 and / or float32 (= u8 / 255).
@@ -418,18 +478,35 @@ MDX_EXPORT int mdx_resample_lanczos_u8(const mdx_resample_job *jobs, int njobs, 
         const int n = njobs - first < MDX_IMG_JOBS ? njobs - first : MDX_IMG_JOBS;
         ResampleJobs a;
         memset(&a, 0, sizeof(a));
-        int max_in_h = 0, max_out_w = 0, max_out_h = 0, n4 = 0;
+        int max_in_h = 0, max_out_w = 0, max_out_h = 0, n4 = 0, n_cols = 0, cols_out_w = 0, taps_out_w = 0;
+        unsigned taps_used = 0;
+        const bool force_cols = getenv("MDX_RESAMPLE_COLUMNS") != nullptr;      // developer switch: A/B and tests
         for (int i = 0; i < n; ++i) {
             static_cast<mdx_resample_job &>(a.j[i]) = jobs[first + i];
             ResampleJob &J = a.j[i];
             J.vec4 = J.out_w % 4 == 0 && aligned(J.inter, 4) && (!J.dst_u8 || aligned(J.dst_u8, 4)) &&
                      (!J.dst_f32 || aligned(J.dst_f32, 16));
             n4 += J.vec4;
+            // horizontal form by filter width (measured on 12 KITTI frames, columns / taps form: 25 taps 28 / 45 us,
+            // 49 taps 36 / 43 us, 95 taps 82 / 31 us): chunked taps for 65..128 taps, lanes along the columns otherwise
+            const int ks = J.xksize;
+            J.h_taps = force_cols || ks <= 64 || ks > 128 ? 0 : (ks <= 96 ? 6 : 8);
+            if (J.h_taps) {
+                taps_used |= J.h_taps == 6 ? 4u : 8u;
+                taps_out_w = J.out_w > taps_out_w ? J.out_w : taps_out_w;
+            } else {
+                ++n_cols;
+                cols_out_w = J.out_w > cols_out_w ? J.out_w : cols_out_w;
+            }
             max_in_h = J.in_h > max_in_h ? J.in_h : max_in_h;
             max_out_w = J.out_w > max_out_w ? J.out_w : max_out_w;
             max_out_h = J.out_h > max_out_h ? J.out_h : max_out_h;
         }
-        hipLaunchKernelGGL(resample_h_kernel, dim3((max_out_w + 63) / 64, (max_in_h + 4 * HR - 1) / (4 * HR), n), dim3(256), 0, st, a);
+        if (n_cols)
+            hipLaunchKernelGGL(resample_h_kernel, dim3((cols_out_w + 63) / 64, (max_in_h + 4 * HR - 1) / (4 * HR), n), dim3(256), 0, st, a);
+        const dim3 tg((taps_out_w + 3) / 4, (max_in_h + HT_ROWS - 1) / HT_ROWS, n);
+        if (taps_used & 4u) hipLaunchKernelGGL(resample_h_taps_kernel<6>, tg, dim3(256), 0, st, a);
+        if (taps_used & 8u) hipLaunchKernelGGL(resample_h_taps_kernel<8>, tg, dim3(256), 0, st, a);
         if (n4)
             hipLaunchKernelGGL(resample_v_kernel<4>, dim3((max_out_w + 1023) / 1024, max_out_h, 3 * n), dim3(256), 0, st, a);
         if (n4 < n)

@@ -75,6 +75,27 @@ def test_resize_lanczos_bit_exact(G, IP, case):
         assert np.array_equal(f32[n].view(np.uint32), orc.to_tensor(ref).view(np.uint32)), "ToTensor %d" % n
 
 
+def test_resize_both_horizontal_forms_agree(G, IP, monkeypatch):
+    """strong reductions take the chunked-taps form of the horizontal pass (a wave per output column), the others the
+    lanes-along-columns form; MDX_RESAMPLE_COLUMNS forces the latter everywhere: same bytes.  Filter widths 25, 49, 95
+    (the KITTI pyramid), 33, 65 and 97 (first widths of the two chunk sizes), 129 (beyond the taps form), with flips."""
+    rng = np.random.default_rng(78)
+    plans = IP.plan_cache("cuda:0")
+    cases = [((375, 1242), (96, 320)), ((375, 1242), (48, 160)), ((375, 1242), (24, 80)), ((21, 1226), (21, 230)),
+             ((9, 1000), (9, 94)), ((9, 1000), (7, 63)), ((5, 1300), (5, 61))]
+    for (h, w), out in cases:
+        imgs = [_natural(rng, h, w), _natural(rng, h, w - 5)]
+        sizes, flips = [(h, w), (h, w - 5)], [False, True]
+        src = torch.from_numpy(_stack(imgs)).cuda()
+        a = IP.resize_lanczos(plans, src, sizes, flips, out, want_u8=True)[0]
+        monkeypatch.setenv("MDX_RESAMPLE_COLUMNS", "1")
+        b = IP.resize_lanczos(plans, src, sizes, flips, out, want_u8=True)[0]
+        monkeypatch.delenv("MDX_RESAMPLE_COLUMNS")
+        assert torch.equal(a, b), ((h, w), out)
+        for n in range(2):
+            assert np.array_equal(a[n].cpu().numpy(), orc.resample_lanczos(imgs[n], out[0], out[1], flips[n]).transpose(2, 0, 1))
+
+
 def test_resize_wide_source(G, IP):
     """a source 350x wider than its output (2101 taps per column)."""
     rng = np.random.default_rng(77)
