@@ -70,7 +70,10 @@ static __device__ __forceinline__ unsigned load32_unaligned(const uint8_t *p)
 // rows; HR x 2 independent loads are in flight); a pixel's three bytes arrive as ONE dword: bytes [3px, 3px+3], or for
 // the last pixel of a row [3px-1, 3px+2] shifted down (never a byte past the row).
 constexpr int HR = 4;
-template <bool FLIP>
+// EDGE: some lane of the wave taps the last pixel of a row (only the last columns do) -- the general form with the
+// shifted load; otherwise every tap is the plain dword at 3*px.  Row bases are wave-uniform (scalar registers), the
+// per-lane part of an address is one 32-bit offset.
+template <bool FLIP, bool EDGE>
 static __device__ __forceinline__ void resample_h_body(const ResampleJob &J, int xo, int y0, bool ok, int lane)
 {
     const int xmin = J.xbounds[2 * xo], n = J.xbounds[2 * xo + 1];
@@ -79,23 +82,29 @@ static __device__ __forceinline__ void resample_h_body(const ResampleJob &J, int
     int s[HR][3];
 #pragma unroll
     for (int r = 0; r < HR; ++r) {
-        row[r] = J.src + (size_t)min(y0 + r, J.in_h - 1) * J.in_stride;
+        row[r] = J.src + (size_t)min(y0 + r, J.in_h - 1) * J.in_stride;      // y0 is wave-uniform
         s[r][0] = s[r][1] = s[r][2] = 1 << (RS_BITS - 1);
     }
     const int last = J.in_w - 1;
+    unsigned off = 3u * (unsigned)(FLIP ? last - xmin : xmin);
 #pragma unroll 2
     for (int t = 0; t < n; ++t) {
         const int c = k[(size_t)t * J.out_w];
-        const int px = FLIP ? last - (xmin + t) : xmin + t;
-        const int edge = px == last ? 1 : 0;
-        const int off = 3 * px - edge;
+        unsigned o = off, sh = 0;
+        if (EDGE) {
+            const bool edge = off == 3u * (unsigned)last;
+            o = off - (edge ? 1u : 0u);
+            sh = edge ? 8u : 0u;
+        }
 #pragma unroll
         for (int r = 0; r < HR; ++r) {
-            const unsigned v = load32_unaligned(row[r] + off) >> (8 * edge);
+            unsigned v = load32_unaligned(row[r] + o);
+            if (EDGE) v >>= sh;
             s[r][0] += __mul24((int)(v & 255u), c);             // |weight| < 2^22: v_mad_i32_i24, full rate
             s[r][1] += __mul24((int)((v >> 8) & 255u), c);
             s[r][2] += __mul24((int)((v >> 16) & 255u), c);
         }
+        off = FLIP ? off - 3u : off + 3u;
     }
     const size_t plane = (size_t)J.in_h * J.out_w;
 #pragma unroll
@@ -117,12 +126,22 @@ __global__ __launch_bounds__(256) void resample_h_kernel(ResampleJobs jobs)
     if (J.h_taps) return;                                            // this job runs in resample_h_taps_kernel
     const int lane = threadIdx.x & 63;
     const int xo0 = blockIdx.x * 64;
-    const int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * HR;
+    // the wave index as a scalar: taken from threadIdx.x alone the compiler treats the row addresses as lane-varying
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int y0 = (blockIdx.y * 4 + wave) * HR;
     if (xo0 >= J.out_w || y0 >= J.in_h) return;                      // wave-uniform: the packed stores need whole waves
     const bool ok = xo0 + lane < J.out_w;
     const int xo = min(xo0 + lane, J.out_w - 1);
-    if (J.flip) resample_h_body<true>(J, xo, y0, ok, lane);
-    else resample_h_body<false>(J, xo, y0, ok, lane);
+    // does any lane tap the last source pixel?  (bounds are monotonic: the last column reaches furthest)
+    const int xl = min(xo0 + 63, J.out_w - 1);
+    const bool edge = J.flip ? J.xbounds[2 * xo0] == 0 : J.xbounds[2 * xl] + J.xbounds[2 * xl + 1] == J.in_w;
+    if (J.flip) {
+        if (edge) resample_h_body<true, true>(J, xo, y0, ok, lane);
+        else resample_h_body<true, false>(J, xo, y0, ok, lane);
+    } else {
+        if (edge) resample_h_body<false, true>(J, xo, y0, ok, lane);
+        else resample_h_body<false, false>(J, xo, y0, ok, lane);
+    }
 }
 
 // Horizontal pass for strong reductions (65..128 taps: the 80-column scale of a 1242-wide frame has 95).  With lanes along the
