@@ -77,7 +77,9 @@ class graphed_step(object):
         torch.cuda.synchronize(dev)
         before = [m._pending_batches for m in self.bns]
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread_local: the DataLoader's pin-memory thread keeps allocating pinned host buffers for the next batches
+        # while this thread captures; in the default "global" mode such a call from ANY thread invalidates the capture
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.outputs = tr._eager_step(dict(self.static))
         self.bn_incr = [m._pending_batches - b for m, b in zip(self.bns, before)]
         torch.cuda.synchronize(dev)
