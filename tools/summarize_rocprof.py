@@ -13,7 +13,8 @@ import sys
 def main():
     src, dst = sys.argv[1], sys.argv[2]
     cmd = sys.argv[3] if len(sys.argv) > 3 else ""
-    f = glob.glob(os.path.join(src, "**", "*_kernel_stats.csv"), recursive=True)[0]
+    # gpurun merges every call's files into the same local directory: take the newest run
+    f = max(glob.glob(os.path.join(src, "**", "*_kernel_stats.csv"), recursive=True), key=os.path.getmtime)
     rows = list(csv.DictReader(open(f)))
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
     lines = ["# rocprofv3 --kernel-trace --stats summary", "# command: " + cmd,
