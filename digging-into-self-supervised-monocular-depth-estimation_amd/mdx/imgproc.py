@@ -59,6 +59,8 @@ class plan_cache(object):
             _lib.check(lib.mdx_resample_plan(key[0], key[1], bounds.ctypes.data_as(C.c_void_p),
                                              kk.ctypes.data_as(C.c_void_p)), "mdx_resample_plan")
             self.plans[key] = (ksize, torch.from_numpy(bounds).to(self.device), torch.from_numpy(kk).to(self.device))
+            # a plan outlives the call and may next be used from another stream (prefetcher / step): finish its upload now
+            torch.cuda.current_stream(self.device).synchronize()
         return self.plans[key]
 
 
