@@ -49,6 +49,8 @@ def options(argv=None):
                         "(bit-equal to Pillow; csrc/imgproc.hip).  auto = on when training on a GPU")
     p.add_argument("--synthetic_raw", action="store_true",
                    help="synthetic dataset hands over KITTI-sized decoded frames (1242x375 uint8), as the KITTI loaders do with gpu_image_prep")
+    p.add_argument("--resume", type=int, default=0,
+                   help="restart after this many finished epochs from ./model_save/<save>/ (weights <key><N>.pt + state<N>.pt)")
     p.add_argument("--synthetic_pool", type=int, default=0, help="synthetic dataset: number of distinct samples kept (0 = all)")
     p.add_argument("--noise", type=str, default="device", choices=["device", "cpu"])
     p.add_argument("--amp", type=str, default="none", choices=["none", "bf16"])

@@ -70,7 +70,26 @@ class control(object):
         if (epoch + 1) % 2 == 0 or (epoch + 1) == self.opt.epoch:
             for key in models:
                 torch.save(models[key].state_dict(), os.path.join(save_directory, key + str(epoch + 1) + ".pt"))
+            # what a restart needs beyond the reference's files (it saves weights only, logger.py:51-68)
+            torch.save({"epoch": epoch + 1, "optimizer": setting.optim["optimizer"].state_dict(),
+                        "scheduler": setting.optim["scheduler"].state_dict()},
+                       os.path.join(save_directory, "state" + str(epoch + 1) + ".pt"))
         if (epoch + 1) == self.opt.epoch:
             for key in self.metric_name:
                 np.save(os.path.join(loss_directory, key + ".npy"), np.asarray(valid_log[key]))
                 np.save(os.path.join(loss_directory, "train_" + key + ".npy"), np.asarray(train_log[key]))
+
+    def resume(self, setting, epoch):
+        """Restart from the files `save` wrote after `epoch` epochs (every rank loads them): network weights from the
+        reference-named `<key><epoch>.pt`, optimiser and scheduler from `state<epoch>.pt`.  -> the epoch to go on with."""
+        save_directory = os.path.join("./model_save", self.opt.save)
+        models = getattr(setting, "raw_model", setting.model)
+        for key in models:
+            path = os.path.join(save_directory, key + str(epoch) + ".pt")
+            if not os.path.exists(path):
+                raise FileNotFoundError("cannot resume from epoch %d: %s is missing" % (epoch, path))
+            models[key].load_state_dict(torch.load(path, map_location=self.device))
+        state = torch.load(os.path.join(save_directory, "state" + str(epoch) + ".pt"), map_location=self.device)
+        setting.optim["optimizer"].load_state_dict(state["optimizer"])
+        setting.optim["scheduler"].load_state_dict(state["scheduler"])
+        return int(state["epoch"])

@@ -158,7 +158,8 @@ class trainer(object):
         names = self.control.metric_name
         epoch_train = {k: [] for k in names}
         epoch_valid = {k: [] for k in names}
-        for epoch in range(self.opt.epoch):
+        start = self.control.resume(self.setting, self.opt.resume) if getattr(self.opt, "resume", 0) else 0
+        for epoch in range(start, self.opt.epoch):
             batch_train = {k: [] for k in names}
             batch_valid = {k: [] for k in names}
             self.setting.set_train()

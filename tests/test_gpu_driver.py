@@ -266,3 +266,35 @@ def test_trainer_on_kitti_tree_gpu_image_prep_equals_pillow_loader(G, tmp_path):
     tr = trainer(opt)
     tr.train()
     assert tr._graphed is not None
+
+
+def test_trainer_restarts_from_its_checkpoint(G, tmp_path, monkeypatch):
+    """--resume: a trainer started with resume=2 loads the files the first run wrote after its second epoch and runs
+    only the remaining epoch (graph replay on: the captured Adam reads the restored moments and learning rate)."""
+    import importlib
+    from model_train import trainer
+    bench = importlib.import_module("bench")
+    monkeypatch.chdir(tmp_path)
+
+    def make(epochs, resume):
+        opt = bench.make_opt(2, height=64, width=96)
+        opt.synthetic_length, opt.max_steps, opt.miopen_find, opt.graph = 8, 2, False, True
+        opt.epoch, opt.scheduler_step, opt.save, opt.resume = epochs, 1, "restart", resume
+        return opt
+
+    torch.manual_seed(0)
+    first = trainer(make(2, 0))
+    first.train()
+    saved = {k: v.clone() for k, v in first.setting.raw_model["decoder"].state_dict().items()}
+    torch.manual_seed(5)
+    second = trainer(make(3, 2))
+    epochs_run = []
+    original = second.control.print
+    second.control.print = lambda epoch, *a: (epochs_run.append(epoch), original(epoch, *a))[1]
+    second.train()
+    assert epochs_run == [2]                                           # only the third epoch ran
+    assert second.setting.optim["scheduler"].last_epoch == 3
+    moved = [k for k, v in second.setting.raw_model["decoder"].state_dict().items() if not torch.equal(v, saved[k])]
+    assert moved                                                       # it trained on from the restored weights
+    lr = second.setting.optim["optimizer"].param_groups[0]["lr"]
+    assert abs(float(lr) - 1e-4 * 0.1 ** 3) < 1e-12

@@ -245,3 +245,55 @@ def test_batched_pose_pairs_equal_the_per_pair_loop():
                 continue
             err, scale = float((p.grad - q.grad).norm()), float(q.grad.norm())
             assert err <= 1e-3 * scale + 1e-7, "%s.%s: %g vs %g" % (name, n, err, scale)
+
+
+def test_checkpoint_resume_restores_weights_optimizer_and_schedule(tmp_path, monkeypatch):
+    """control.save writes the reference-named weight files (+ state<N>.pt); control.resume restores networks, Adam
+    moments and the StepLR position: a step after the restart equals the step the uninterrupted run takes."""
+    import types
+    from model_tool import setting, compute, control
+    from cpu_loss import cpu_compute_loss
+    monkeypatch.chdir(tmp_path)
+
+    def make(seed):
+        o = types.SimpleNamespace(dataset="synthetic", datatype="x", datapath="", splits="", batch=2, height=64, width=96,
+                                  scales=[0, 1, 2, 3], frame_ids=[0, -1, 1], min_depth=0.1, max_depth=100.0,
+                                  disp_smoothness=1e-3, use_automasking=True, pose_type="separate", pose_frames="pair",
+                                  num_layers=18, weight_init=False, learning_rate=1e-3, scheduler_step=1, epoch=4,
+                                  save="resume_test", num_workers=0, synthetic_length=4, fused=True, noise="device",
+                                  amp="none")
+        torch.manual_seed(seed)
+        return o, setting(o, "cpu"), compute(o, "cpu"), control(o, "cpu")
+
+    def step(o, st, cp, inputs):
+        out = {}
+        i, out = cp.forward_depth(dict(inputs), out, st)
+        i, out = cp.forward_pose(i, out, st)
+        st.optim["optimizer"].zero_grad(set_to_none=True)
+        cpu_compute_loss(o, i, out, seed=3).backward()
+        st.optim["optimizer"].step()
+
+    o, st, cp, ct = make(1)
+    st.set_train()
+    inputs = next(iter(st.train_dataloader))
+    for _ in range(2):
+        step(o, st, cp, inputs)
+        st.optim["scheduler"].step()
+    empty = {k: [] for k in ct.metric_name}
+    ct.save(1, empty, empty, st)                                   # after the second epoch
+    files = sorted(os.listdir(os.path.join("model_save", "resume_test")))
+    assert {"encoder2.pt", "decoder2.pt", "pose_encoder2.pt", "pose_decoder2.pt", "state2.pt"} <= set(files)
+    o2, st2, cp2, ct2 = make(99)                                   # different initial weights
+    assert ct2.resume(st2, 2) == 2
+    st2.set_train()
+    assert st2.optim["scheduler"].get_last_lr() == st.optim["scheduler"].get_last_lr() != [1e-3]
+    for key in st.raw_model:
+        for (n, a), (_, b) in zip(st.raw_model[key].state_dict().items(), st2.raw_model[key].state_dict().items()):
+            assert torch.equal(a, b), (key, n)
+    step(o, st, cp, inputs)
+    step(o2, st2, cp2, inputs)
+    for key in st.raw_model:
+        for (n, a), (_, b) in zip(st.raw_model[key].named_parameters(), st2.raw_model[key].named_parameters()):
+            assert torch.allclose(a, b, rtol=0, atol=1e-7), (key, n)
+    with pytest.raises(FileNotFoundError):
+        ct2.resume(st2, 3)
