@@ -163,6 +163,44 @@ MDX_DEV SsimBoth ssim_both(const SsimTerms &s, const TargetStats &t, float gscal
     return r;
 }
 
+// ---- the item's 3x4 matrices as TRANSIENT scalars ----
+// P (S x 12) and invK (12) are wave-uniform.  Held in scalar registers for the whole item they take 36 of the ~100
+// SGPRs; with the row pointers of a step on top the allocator spilled 61 values to VGPR lanes and paid ~90
+// v_readlane / v_writelane (VALU issue slots, plus hazard s_nops) per step.  MDX_TRAIN_SLOAD re-reads them through
+// the scalar cache where they are used (s_load_dwordx4 x3 per matrix, scalar unit, no VALU slot) so that they are dead
+// in between: 61 -> 41 spilled SGPRs, 120 -> 45 v_readlane, 165 -> 116 s_nop cycles in the kernel, -1.5 % time.
+// (=0 keeps the old form for A/B builds.)
+#ifndef MDX_TRAIN_SLOAD
+#define MDX_TRAIN_SLOAD 1
+#endif
+#ifndef MDX_TRAIN_OPAQUE_HW
+#define MDX_TRAIN_OPAQUE_HW 1
+#endif
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+struct SRows {
+    f32x4 a, b, c;
+};
+static __device__ __forceinline__ const float *uniform_ptr(const float *p)
+{
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return (const float *)(((unsigned long long)hi << 32) | lo);
+}
+static __device__ __forceinline__ void sload12(const float *p, SRows &m)
+{
+    asm volatile("s_load_dwordx4 %0, %3, 0x0\n\ts_load_dwordx4 %1, %3, 0x10\n\ts_load_dwordx4 %2, %3, 0x20"
+                 : "=&s"(m.a), "=&s"(m.b), "=&s"(m.c)
+                 : "s"(p));
+}
+static __device__ __forceinline__ void swait12(SRows &m, float *o)     // the loads above have landed; o = the 12 floats
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(m.a), "+s"(m.b), "+s"(m.c));
+    o[0] = m.a.x; o[1] = m.a.y; o[2] = m.a.z; o[3] = m.a.w;
+    o[4] = m.b.x; o[5] = m.b.y; o[6] = m.b.z; o[7] = m.b.w;
+    o[8] = m.c.x; o[9] = m.c.y; o[10] = m.c.z; o[11] = m.c.w;
+}
+
 template <int S>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S <= 2 ? 3 : 2, S <= 2 ? 3 : 2))) void photometric_train_kernel(TrainArgs a)
 {
@@ -191,7 +229,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S <= 2 ? 3 :
     d.h = pick(a.h, scale);
     d.w = pick(a.w, scale);
     const int H = d.H, W = d.W;
-    const size_t HW = (size_t)H * W;
+    const size_t HW0 = (size_t)H * W;
+    // Inside the row loop the plane size is made opaque once per step (MDX_TRAIN_OPAQUE_HW): otherwise the dozen plane
+    // bases `tensor + (b*planes + c)*HW` are hoisted out of the loop as 64-bit scalars -- and spilled to VGPR lanes;
+    // recomputing them per step costs scalar-unit instructions only.
+    unsigned HW = (unsigned)HW0;
     const float *disp_b = pick(a.disp, scale) + (size_t)b * d.h * d.w;
     const float *P_s = pick(a.P, scale);
     const float *noise_s = pick(a.noise, scale);
@@ -199,7 +241,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S <= 2 ? 3 :
     float *gup_s = pick(a.gup, scale);
     float *to_opt_s = pick(a.to_opt, scale);
     const float *invK_b = a.invK + b * 16;
-    const float *tgt_b = a.target + (size_t)b * 3 * HW;
+    const float *tgt_b = a.target + (size_t)b * 3 * HW0;
     const bool automask = (d.flags & MDX_FLAG_AUTOMASK) != 0;
     const bool premul = (d.flags & MDX_FLAG_UPSAMPLE_PREMUL) != 0;
     const bool same_res = d.h == H && d.w == W;
@@ -221,6 +263,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S <= 2 ? 3 :
 
     // ---- the item's matrices, once, as wave-uniform scalars (inside the loop they would be re-fetched through vector
     //      memory every row and consumed at once: two exposed cache round trips per row) ----
+#if MDX_TRAIN_SLOAD
+    const float *Pp[S];
+#pragma unroll
+    for (int f = 0; f < S; ++f) Pp[f] = uniform_ptr(P_s + ((size_t)f * d.B + b) * 12);
+    const float *iKp = uniform_ptr(invK_b);
+#else
     float Pm[S][12], iK[12];
 #pragma unroll
     for (int f = 0; f < S; ++f)
@@ -231,6 +279,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S <= 2 ? 3 :
 #pragma unroll
     for (int k = 0; k < 12; ++k)
         iK[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, invK_b[k])));
+#endif
 
     // ---- histories (registers) ----
     float xh[3][S][3];   // warped colours, rows wr-2 .. wr
@@ -267,7 +316,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S <= 2 ? 3 :
         const int pyr = reflect(min(max(wr, -1), H), H);
         const unsigned po = (unsigned)(pyr * W + pxr);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) pf_y[c] = at32(tgt_b + c * HW, po);
+        for (int c = 0; c < 3; ++c) pf_y[c] = at32(tgt_b + (size_t)c * HW, po);
         if (same_res) {
             pf_d[0] = at32(disp_b, po);
         } else {
@@ -305,6 +354,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S <= 2 ? 3 :
         const int sr = wr - 1;            // row whose SSIM / arg-min / coefficients are formed
         const int gr = wr - 2;            // row whose gradient is formed
         const int slot_w = t % 3, slot_r = (t + 1) % 3;
+#if MDX_TRAIN_OPAQUE_HW
+        asm volatile("" : "+s"(HW));
+#endif
+#if MDX_TRAIN_SLOAD
+        SRows s_iK, s_P[S];
+        sload12(iKp, s_iK);
+#pragma unroll
+        for (int f = 0; f < S; ++f) sload12(Pp[f], s_P[f]);
+#endif
 
         // ================= (1) warp row wr =================
 #pragma unroll
@@ -327,6 +385,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S <= 2 ? 3 :
                 const UpTap ty = up_tap((float)d.h / (float)H, pyr, d.h);
                 up = up_combine(pf_d[0], pf_d[1], pf_d[2], pf_d[3], ty, tx, premul);
             }
+#if MDX_TRAIN_SLOAD
+            float iK[12], Pm[S][12];
+            swait12(s_iK, iK);
+#pragma unroll
+            for (int f = 0; f < S; ++f) swait12(s_P[f], Pm[f]);
+#endif
             const PixelGeom g = geom_from_disp(d, up, iK, pxr, pyr);
             dph[2] = g.depth;
             if (a.depth0 && scale == 0 && out_lane && wr >= r0 && wr < r1)
@@ -478,6 +542,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S <= 2 ? 3 :
         // ================= (3) gradient of row gr =================
         if (t < 4) continue;
         const float wy0 = gr == 1 ? 2.f : 1.f, wy2 = gr == H - 2 ? 2.f : 1.f;   // reflection-pad fold (y)
+#if MDX_TRAIN_SLOAD
+        float iK[12], Pm[S][12];
+        {   // re-read right here: issued before the SSIM phase, or kept from the top of the step, the longer live
+            // ranges cost more in spills than the exposed scalar-cache latency (300 us against 314 / 312 us, kbench)
+            SRows g_iK, g_P[S];
+            sload12(iKp, g_iK);
+#pragma unroll
+            for (int f = 0; f < S; ++f) sload12(Pp[f], g_P[f]);
+            swait12(g_iK, iK);
+#pragma unroll
+            for (int f = 0; f < S; ++f) swait12(g_P[f], Pm[f]);
+        }
+#endif
         float r3[3];
         pixel_ray(iK, fpx, (float)gr, r3);
         const float depth = dph[0];
@@ -574,6 +651,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S <= 2 ? 3 :
             const float sB = wave_sum_dpp_lane63(accB[f][i]);
             const float sC = wave_sum_dpp_lane63(accC[f][i]);
             if (lane == 63) {
+#if MDX_TRAIN_SLOAD
+                const float *iK = invK_b;
+#endif
                 float *o = a.partP + (size_t)item * (S * 12) + f * 12 + i * 4;
 #pragma unroll
                 for (int j = 0; j < 3; ++j)
