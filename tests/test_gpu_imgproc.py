@@ -150,8 +150,11 @@ def test_color_jitter_bit_exact(G, IP):
             assert np.array_equal(out[n].view(np.uint32), orc.to_tensor(ref).view(np.uint32)), "image %d" % n
 
 
-def test_image_prep_equals_cpu_loader_arithmetic(G, IP):
-    """the batch-level stage against what the CPU loader computes per sample with Pillow (model_loader/kitti.py)."""
+@pytest.mark.parametrize("hw", [(192, 640), (320, 1024)])
+def test_image_prep_equals_cpu_loader_arithmetic(G, IP, hw):
+    """the batch-level stage against what the CPU loader computes per sample with Pillow (model_loader/kitti.py), at
+    both BASELINE resolutions."""
+    H, W = hw
     from model_loader.kitti import ColorJitter, to_tensor
     rng = np.random.default_rng(9)
     B, frames, sizes = 3, [0, -1, 1], [(375, 1242), (370, 1226), (376, 1241)]
@@ -162,7 +165,7 @@ def test_image_prep_equals_cpu_loader_arithmetic(G, IP):
     batch = {("raw", f): torch.from_numpy(_stack(raw[f])) for f in frames}
     batch.update({"raw_size": torch.tensor(sizes, dtype=torch.int32), "raw_flip": torch.tensor(flips),
                   "raw_jitter": torch.tensor(rows, dtype=torch.float64), ("K", 0): torch.eye(4).repeat(B, 1, 1)})
-    prep = IP.image_prep(192, 640, frames, 4, "cuda:0")
+    prep = IP.image_prep(H, W, frames, 4, "cuda:0")
     out = prep(batch)
     assert ("raw", 0) not in out and "raw_size" not in out and ("K", 0) in out
     for f in frames:
@@ -171,7 +174,7 @@ def test_image_prep_equals_cpu_loader_arithmetic(G, IP):
             if flips[b]:
                 im = im.transpose(Image.FLIP_LEFT_RIGHT)
             for s in range(4 if f == 0 else 1):
-                small = im.resize((640 >> s, 192 >> s), Image.LANCZOS)
+                small = im.resize((W >> s, H >> s), Image.LANCZOS)
                 assert torch.equal(out[("color", f, s)][b].cpu(), to_tensor(small)), (f, b, s)
                 if s == 0:
                     aug = to_tensor(jit[b](small)) if jit[b] is not None else to_tensor(small)
