@@ -36,8 +36,7 @@ assert RESAMPLE_JOB.itemsize == 96 and JITTER_JOB.itemsize == 72
 
 
 def _check_u8(t, what):
-    if not (torch.is_tensor(t) and t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous()):
-        raise _lib.MdxError("%s must be a contiguous uint8 tensor on the GPU (there is no CPU fallback)" % what)
+    _lib.ptr(t, torch.uint8)          # GPU, contiguous, uint8, on the CURRENT device (whose stream the library is given)
 
 
 class plan_cache(object):
@@ -135,6 +134,7 @@ def color_jitter(src_u8, params, out=None):
     dev = src_u8.device
     if out is None:
         out = torch.empty(N, 3, h, w, dtype=torch.float32, device=dev)
+    _lib.ptr(out, torch.float32)
     todo = [n for n in range(N) if params[n] is not None]
     if not todo:
         return out
