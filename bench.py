@@ -515,7 +515,7 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import loader_cost
             line["image_prep"] = loader_cost.measure(samples=12, batch=args.batch, reps=10, height=args.height,
-                                                     width=args.width, frames=[f for f in frame_ids])
+                                                     width=args.width, frames=[f for f in frame_ids], workers=args.workers)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))

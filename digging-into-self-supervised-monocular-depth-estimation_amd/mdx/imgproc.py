@@ -7,7 +7,9 @@ per frame next to 3.7 ms of JPEG decoding.  Here the workers only decode; the ba
 (processor.step_reads): ("color", f, 0), ("color_aug", f, 0) for every frame and ("color", 0, s), s = 1..3 -- bit-equal
 to Pillow's output divided by 255.
 
-    batch keys consumed:  ("raw", f)  uint8 [B, hmax, wmax, 3]      "raw_size" int32 [B, 2] (h, w), CPU
+    batch keys consumed:  ("depth_idx", 0) int32 [B, n] / ("depth_val", 0) float32 [B, n]: sparse velodyne ground truth
+                          (padding: index h*w) + "depth_hw" [B, 2], CPU  ->  ("depth", 0) [B,1,h,w]
+                          ("raw", f)  uint8 [B, hmax, wmax, 3]      "raw_size" int32 [B, 2] (h, w), CPU
                           "raw_flip"  bool [B], CPU                  "raw_jitter" float64 [B, 9], CPU:
                                                                        (enabled, order[4], brightness, contrast,
                                                                         saturation, hue_shift)
@@ -194,8 +196,15 @@ class image_prep(object):
         flips = [bool(v) for v in batch["raw_flip"].tolist()]
         params = [jitter_params(row) for row in batch["raw_jitter"].tolist()]
         any_jitter = any(p is not None for p in params)
-        out = {k: v for k, v in batch.items()
-               if not (isinstance(k, tuple) and k[0] == "raw") and k not in ("raw_size", "raw_flip", "raw_jitter")}
+        drop = ("raw_size", "raw_flip", "raw_jitter", "depth_hw", ("depth_idx", 0), ("depth_val", 0))
+        out = {k: v for k, v in batch.items() if not (isinstance(k, tuple) and k[0] == "raw") and k not in drop}
+        if ("depth_idx", 0) in batch:     # sparse velodyne ground truth -> the dense [B,1,h,w] map the loader's contract names
+            gh, gw = (int(v) for v in batch["depth_hw"][0].tolist())
+            idx = batch[("depth_idx", 0)].to(self.device, non_blocking=True).long()
+            val = batch[("depth_val", 0)].to(self.device, non_blocking=True)
+            buf = torch.zeros(idx.shape[0], gh * gw + 1, device=self.device)       # + one slot that takes the padding
+            buf.scatter_(1, idx, val)
+            out[("depth", 0)] = buf[:, :gh * gw].reshape(-1, 1, gh, gw).contiguous()
         sources = []
         for f in self.frame_ids:
             raw = batch[("raw", f)]

@@ -38,7 +38,7 @@ def step_reads(key):
     return True                                             # ("depth", 0), injected test entries
 
 
-HOST_KEYS = ("raw_size", "raw_flip", "raw_jitter")     # read on the host by mdx.imgproc.image_prep: never uploaded
+HOST_KEYS = ("raw_size", "raw_flip", "raw_jitter", "depth_hw")     # read on the host by mdx.imgproc.image_prep: never uploaded
 
 
 def device_key(key):

@@ -85,5 +85,11 @@ class SyntheticKITTI(Dataset):
         gt = torch.zeros(1, *self.gt_size)
         m = torch.rand(1, *self.gt_size, generator=g) < 0.05
         gt[m] = 1 + 79 * torch.rand(int(m.sum()), generator=g)
-        inputs[("depth", 0)] = gt
+        if self.raw:           # as model_loader.kitti with gpu_prep: (pixel index, value) pairs
+            flat = gt.reshape(-1)
+            idx = torch.nonzero(flat).reshape(-1)
+            inputs[("depth_idx", 0)], inputs[("depth_val", 0)] = idx.to(torch.int32), flat[idx]
+            inputs["depth_hw"] = torch.tensor(self.gt_size, dtype=torch.int32)
+        else:
+            inputs[("depth", 0)] = gt
         return inputs

@@ -219,5 +219,6 @@ def test_kitti_loader_gpu_prep_equals_pillow_path(G, IP, tmp_path):
                 assert torch.equal(value[b].cpu(), ref[b][key]), (key, b)
     for b in range(len(names)):
         assert torch.equal(out["stereo"][b], ref[b]["stereo"])
+        assert torch.equal(out[("depth", 0)][b].cpu(), ref[b][("depth", 0)])          # scattered from the sparse pairs
     wanted = {k for k in ref[0] if step_reads(k)}
     assert wanted == set(out.keys()), wanted ^ set(out.keys())

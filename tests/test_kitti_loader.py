@@ -83,7 +83,10 @@ def test_gpu_prep_mode_hands_over_decoded_frames(tmp_path):
         assert not any(isinstance(k, tuple) and k[0] in ("color", "color_aug") for k in b)
         assert b[("raw", 0)].shape == (375, 1242, 3) and b[("raw", 0)].dtype == torch.uint8
         assert b["raw_size"].tolist() == [375, 1242]
-        assert torch.equal(a[("depth", 0)], b[("depth", 0)]) and torch.equal(a[("K", 0)], b[("K", 0)])
+        assert torch.equal(a[("K", 0)], b[("K", 0)]) and ("depth", 0) not in b
+        dense = torch.zeros(375 * 1242)
+        dense[b[("depth_idx", 0)].long()] = b[("depth_val", 0)]                 # sparse ground truth == the dense map
+        assert torch.equal(dense.reshape(1, 375, 1242), a[("depth", 0)]) and b["depth_hw"].tolist() == [375, 1242]
         # the frame is handed over unflipped and undistorted by augmentation: Pillow on it reproduces the CPU entry
         im = Image.fromarray(b[("raw", -1)].numpy())
         if bool(b["raw_flip"]):
@@ -100,4 +103,9 @@ def test_gpu_prep_mode_hands_over_decoded_frames(tmp_path):
     assert batch[("raw", 1)].shape == (2, 375, 1242, 3) and batch["raw_size"].tolist() == [[375, 1242], [370, 1226]]
     assert (batch[("raw", 1)][1, 370:] == 0).all() and (batch[("raw", 1)][1, :, 1226:] == 0).all()
     assert ("K", 1) not in batch and batch["raw_jitter"].shape == (2, 9)
+    n = max(int(raw[1][("depth_idx", 0)].numel()), int(small[("depth_idx", 0)].numel()))
+    assert batch[("depth_idx", 0)].shape == (2, n) == batch[("depth_val", 0)].shape
+    short = 0 if raw[1][("depth_idx", 0)].numel() < n else 1
+    k = int((raw[1] if short == 0 else small)[("depth_idx", 0)].numel())
+    assert (batch[("depth_idx", 0)][short, k:] == 375 * 1242).all() and (batch[("depth_val", 0)][short, k:] == 0).all()
     assert step_reads("raw_size") and not device_key("raw_size") and device_key(("raw", 0))

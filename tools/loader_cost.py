@@ -25,7 +25,7 @@ import torch  # noqa: E402
 importlib.import_module("digging-into-self-supervised-monocular-depth-estimation_amd")
 
 
-def measure(samples=24, batch=12, reps=20, height=192, width=640, frames=(0, -1, 1)):
+def measure(samples=24, batch=12, reps=20, height=192, width=640, frames=(0, -1, 1), workers=0):
     import fake_kitti
     from model_loader import KITTIMonoDataset_v2
     from model_loader.kitti import collate_raw
@@ -51,6 +51,39 @@ def measure(samples=24, batch=12, reps=20, height=192, width=640, frames=(0, -1,
             ms = 1e3 * (time.perf_counter() - t0) / samples
             out["host_ms_per_sample_" + mode] = round(ms, 2)
             out["host_samples_per_s_per_core_" + mode] = round(1e3 / ms, 1)
+        if workers > 0:
+            # the DataLoader itself (worker processes, collate, pinned memory) on the cores this process may use
+            from torch.utils.data import DataLoader, Dataset
+            from model_tool.loader import collate_step_keys, collate_raw_step_keys
+
+            class Repeat(Dataset):
+                def __init__(self, ds, n):
+                    self.ds, self.n = ds, n
+
+                def __len__(self):
+                    return self.n
+
+                def __getitem__(self, i):
+                    return self.ds[i % len(self.ds)]
+
+            out["loader_workers"] = workers
+            out["loader_cores_available"] = len(os.sched_getaffinity(0))
+            for mode in ("pillow", "gpu_prep"):
+                ds = KITTIMonoDataset_v2(root, names, True, frames, height, width, "jpg", 4)
+                ds.uint8, ds.gpu_prep = True, mode == "gpu_prep"
+                nb = 8 if mode == "pillow" else 40
+                loader = DataLoader(Repeat(ds, (nb + 2 * workers) * batch), batch, False, num_workers=workers, drop_last=True,
+                                    pin_memory=torch.cuda.is_available(), prefetch_factor=2,
+                                    collate_fn=collate_raw_step_keys if ds.gpu_prep else collate_step_keys)
+                it = iter(loader)
+                for _ in range(workers // 2 + 1):             # the workers' first batches (imports, page cache)
+                    next(it)
+                t0 = time.perf_counter()
+                for _ in range(nb):
+                    next(it)
+                dt = time.perf_counter() - t0
+                out["loader_samples_per_s_" + mode] = round(nb * batch / dt, 1)
+                del it, loader
         if torch.cuda.is_available():
             from mdx import imgproc
             random.seed(1)
@@ -92,8 +125,9 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--height", type=int, default=192)
     ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--workers", type=int, default=0, help="also time the DataLoader with this many worker processes")
     a = ap.parse_args()
-    print(json.dumps(measure(a.samples, a.batch, a.reps, a.height, a.width)))
+    print(json.dumps(measure(a.samples, a.batch, a.reps, a.height, a.width, workers=a.workers)))
 
 
 if __name__ == "__main__":

@@ -14,7 +14,7 @@ if [ "$1" = "--collect" ]; then
     exit 0
 fi
 mkdir -p "$OUT" && cd /tmp && export TMPDIR=/tmp
-python3 "$ROOT/tools/loader_cost.py" > "$OUT/loader_cost.json" 2> "$OUT/loader_cost.err" || exit 1
+python3 "$ROOT/tools/loader_cost.py" --workers 12 > "$OUT/loader_cost.json" 2> "$OUT/loader_cost.err" || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$ROOT/tools/loader_cost.py" --samples 2 --reps 20 > "$OUT/trace.log" 2>&1 || exit 1
 cat "$OUT/loader_cost.json"
 f=$(find "$OUT/trace" -name "*kernel_stats.csv" | head -1)
