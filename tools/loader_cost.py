@@ -35,7 +35,8 @@ def measure(samples=24, batch=12, reps=20, height=192, width=640, frames=(0, -1,
     frames = list(frames)
     out = {"cores": 1, "host_cores": os.cpu_count(), "frames_per_sample": len(frames),
            "what": "KITTIDataset.__getitem__ on one core, %d JPEG frames of 1242x375 per sample (velodyne projection "
-                   "excluded: the same in every mode); pillow = decode + 4 Lanczos resizes + colour jitter + ToTensor per "
+                   "excluded there: the same in every mode; included in loader_samples_per_s_*, the DataLoader with worker "
+                   "processes, collate and pinned memory); pillow = decode + 4 Lanczos resizes + colour jitter + ToTensor per "
                    "frame (the reference's loader), gpu_prep = decode only" % len(frames)}
     with tempfile.TemporaryDirectory() as root:
         names = fake_kitti.make(root, n_frames=samples + 2)
@@ -51,6 +52,36 @@ def measure(samples=24, batch=12, reps=20, height=192, width=640, frames=(0, -1,
             ms = 1e3 * (time.perf_counter() - t0) / samples
             out["host_ms_per_sample_" + mode] = round(ms, 2)
             out["host_samples_per_s_per_core_" + mode] = round(1e3 / ms, 1)
+        if torch.cuda.is_available():
+            from mdx import imgproc
+            random.seed(1)
+            raw = collate_raw([ds[i % len(ds)] for i in range(batch)], step_reads)
+            raw = {k: (v.cuda() if isinstance(k, tuple) and k[0] == "raw" else v) for k, v in raw.items()}
+            prep = imgproc.image_prep(height, width, frames, 4, "cuda:0")
+            jittered = int(raw["raw_jitter"][:, 0].sum())
+            for _ in range(3):
+                prep(raw)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            e0.record()
+            for _ in range(reps):
+                prep(raw)
+            e1.record()
+            host_ms = 1e3 * (time.perf_counter() - t0) / reps
+            e1.synchronize()
+            us = 1e3 * e0.elapsed_time(e1) / reps
+            h, w = (int(v) for v in raw["raw_size"][0])
+            # algorithmic bytes: every source byte once; float32 entries out: scale 0 of every frame, scales 1-3 of the
+            # target, colour_aug of the jittered samples
+            pyramid = sum((height >> s) * (width >> s) for s in range(1, 4))
+            alg = batch * len(frames) * h * w * 3 + 12 * (batch * len(frames) * height * width + batch * pyramid
+                                                          + jittered * len(frames) * height * width)
+            out.update({"gpu_us_per_batch": round(us, 1), "batch": batch, "jittered_samples_in_batch": jittered,
+                        "gpu_host_ms_per_batch": round(host_ms, 2), "alg_bytes_per_batch": alg,
+                        "achieved_GBs": round(alg / us / 1e3, 1), "frac_of_hbm_peak": round(alg / us / 1e3 / 8000.0, 4),
+                        "kernels": "csrc/imgproc.hip: resample_h_kernel, resample_h_taps_kernel<6>, resample_v_kernel<4>, "
+                                   "jitter_mean_kernel, jitter_apply_kernel (profiles/*_imgproc_kernel_stats.txt)"})
         if workers > 0:
             # the DataLoader itself (worker processes, collate, pinned memory) on the cores this process may use
             from torch.utils.data import DataLoader, Dataset
@@ -84,36 +115,6 @@ def measure(samples=24, batch=12, reps=20, height=192, width=640, frames=(0, -1,
                 dt = time.perf_counter() - t0
                 out["loader_samples_per_s_" + mode] = round(nb * batch / dt, 1)
                 del it, loader
-        if torch.cuda.is_available():
-            from mdx import imgproc
-            random.seed(1)
-            raw = collate_raw([ds[i % len(ds)] for i in range(batch)], step_reads)
-            raw = {k: (v.cuda() if isinstance(k, tuple) and k[0] == "raw" else v) for k, v in raw.items()}
-            prep = imgproc.image_prep(height, width, frames, 4, "cuda:0")
-            jittered = int(raw["raw_jitter"][:, 0].sum())
-            for _ in range(3):
-                prep(raw)
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            t0 = time.perf_counter()
-            e0.record()
-            for _ in range(reps):
-                prep(raw)
-            e1.record()
-            host_ms = 1e3 * (time.perf_counter() - t0) / reps
-            e1.synchronize()
-            us = 1e3 * e0.elapsed_time(e1) / reps
-            h, w = (int(v) for v in raw["raw_size"][0])
-            # algorithmic bytes: every source byte once; float32 entries out: scale 0 of every frame, scales 1-3 of the
-            # target, colour_aug of the jittered samples
-            pyramid = sum((height >> s) * (width >> s) for s in range(1, 4))
-            alg = batch * len(frames) * h * w * 3 + 12 * (batch * len(frames) * height * width + batch * pyramid
-                                                          + jittered * len(frames) * height * width)
-            out.update({"gpu_us_per_batch": round(us, 1), "batch": batch, "jittered_samples_in_batch": jittered,
-                        "gpu_host_ms_per_batch": round(host_ms, 2), "alg_bytes_per_batch": alg,
-                        "achieved_GBs": round(alg / us / 1e3, 1), "frac_of_hbm_peak": round(alg / us / 1e3 / 8000.0, 4),
-                        "kernels": "csrc/imgproc.hip: resample_h_kernel, resample_h_taps_kernel<6>, resample_v_kernel<4>, "
-                                   "jitter_mean_kernel, jitter_apply_kernel (profiles/*_imgproc_kernel_stats.txt)"})
     torch.set_num_threads(threads)
     return out
 
