@@ -79,14 +79,17 @@ def point2depth(calib_path, point_path, cam=2, vel_depth=False):
     # row*n + col: besides true duplicates, (row, 0) and (row-1, n-1) share an index -- then the first point's pixel
     # receives the minimum over both pixels' points and the other pixel keeps its last-written value.  Reproduced as is
     # (evaluation numbers are defined by it); vectorised: groups by np.unique, minimum per group, first member's pixel.
-    lin = pts[:, 1] * (depth.shape[1] - 1) + pts[:, 0] - 1
-    _, first, inverse, counts = np.unique(lin, return_index=True, return_inverse=True, return_counts=True)
-    inverse = inverse.reshape(-1)
-    if (counts > 1).any():
-        mins = np.full(len(counts), np.inf)
-        np.minimum.at(mins, inverse, pts[:, 2])
-        grp = np.flatnonzero(counts > 1)
-        depth[ys[first[grp]], xs[first[grp]]] = mins[grp]
+    # (the keys are small integers: bincount finds the few points that share an index, and only those are sorted)
+    lin = ys * (depth.shape[1] - 1) + xs                             # the reference's index + 1 (>= 0)
+    counts = np.bincount(lin, minlength=depth.shape[0] * depth.shape[1] + 1)
+    dup = counts[lin] > 1
+    if dup.any():
+        order = np.flatnonzero(dup)                                  # ascending point order: return_index = first member
+        _, first, inverse = np.unique(lin[order], return_index=True, return_inverse=True)
+        mins = np.full(len(first), np.inf)
+        np.minimum.at(mins, inverse.reshape(-1), pts[order, 2])
+        head = order[first]
+        depth[ys[head], xs[head]] = mins
     depth[depth < 0] = 0
     return depth
 
