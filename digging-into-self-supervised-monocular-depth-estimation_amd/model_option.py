@@ -16,7 +16,9 @@ def options(argv=None):
     p.add_argument("--epoch", type=int, default=24)
     p.add_argument("--batch", type=int, default=12)
     p.add_argument("--prepetch", type=int, default=2)
-    p.add_argument("--num_workers", type=int, default=4)
+    p.add_argument("--num_workers", type=int, default=12,
+                   help="DataLoader workers per process (reference default, model_option.py:32-34).  With --gpu_image_prep 12 "
+                        "workers deliver ~700-800 samples/s, 16 ~1100 (tools/loader_cost.py --workers N)")
     p.add_argument("--learning_rate", type=float, default=1e-4)
     p.add_argument("--scheduler_step", type=int, default=15)
     p.add_argument("--disp_smoothness", type=float, default=1e-3)
