@@ -176,6 +176,9 @@ MDX_DEV SsimBoth ssim_both(const SsimTerms &s, const TargetStats &t, float gscal
 #ifndef MDX_TRAIN_OPAQUE_HW
 #define MDX_TRAIN_OPAQUE_HW 1
 #endif
+#ifndef MDX_TRAIN_XCD_GROUP
+#define MDX_TRAIN_XCD_GROUP 1
+#endif
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct SRows {
     f32x4 a, b, c;
@@ -208,18 +211,43 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S <= 2 ? 3 :
     __shared__ float4 s_stash[3][2 * S][64];
 
     const int lane = threadIdx.x;
-    // ---- work item: level-major order (see TrainArgs), dispatched in block order.  Consecutive items (neighbouring
-    //      strips) go to different XCDs; an XCD-contiguous order inside each level was measured and is WORSE here
-    //      (fabric-side fetch 1.36 GB instead of 1.0 GB per launch, 349 us instead of 320 us on tools/kbench.py's data:
-    //      a contiguous run holds items of equal cost, and the XCDs drift apart) ----
+    // ---- work item: level-major order (see TrainArgs), dispatched in block order.  An XCD-contiguous order inside each
+    //      level (neighbouring strips on one XCD) was measured and is WORSE (fabric-side fetch 1.36 GB instead of 1.0 GB
+    //      per launch, 349 us instead of 320 us on tools/kbench.py's data: a contiguous run holds items of equal cost,
+    //      and the XCDs drift apart); grouping the SCALES of a region on one XCD (below) keeps the balance and cuts the
+    //      fetch to 0.65 GB ----
     const int item_d = (int)blockIdx.x;
     const int lev = item_d >= a.lev_item0[2] ? 2 : (item_d >= a.lev_item0[1] ? 1 : 0);
     const int lev_first = lev == 2 ? a.lev_item0[2] : (lev == 1 ? a.lev_item0[1] : a.lev_item0[0]);
     const int lev_rows = lev == 2 ? a.lev_r[2] : (lev == 1 ? a.lev_r[1] : a.lev_r[0]);
+#if MDX_TRAIN_XCD_GROUP
+    // Workgroup i runs on XCD i % 8.  The scales of one (chunk, image, strip) read the same target / source / identity
+    // rows: their ids share the residue mod 8 and are adjacent (start together), so three of the four find those
+    // lines in the XCD's L2.  Groups go round the XCDs one by one -- every XCD keeps the same mix of costs (what the
+    // XCD-contiguous order lost).
+    const int j = item_d - lev_first;
+    const int per_scale = a.nstrips * a.B, ns = a.ncols / per_scale;
+    const int ngroups = (lev == 2 ? a.lev_n[2] : (lev == 1 ? a.lev_n[1] : a.lev_n[0])) * per_scale;
+    const int full = ngroups / 8, blk = 8 * ns;
+    int grp, scale;
+    if (j < full * blk) {
+        const int q = j / blk, r = j - q * blk;
+        scale = r >> 3;
+        grp = q * 8 + (r & 7);
+    } else {
+        const int jj = j - full * blk, rem = ngroups - full * 8;
+        scale = jj / rem;
+        grp = full * 8 + jj % rem;
+    }
+    const int kk = grp / per_scale, gcol = grp % per_scale;
+    const int strip = gcol % a.nstrips;
+    const int b = gcol / a.nstrips;
+#else
     const int kk = (item_d - lev_first) / a.ncols, colid = (item_d - lev_first) % a.ncols;
     const int strip = colid % a.nstrips;
     const int b = (colid / a.nstrips) % a.B;
     const int scale = colid / (a.nstrips * a.B);
+#endif
     const int chunk = (lev == 2 ? a.lev_k0[2] : (lev == 1 ? a.lev_k0[1] : a.lev_k0[0])) + kk;
     // slot of the item's partials: the items of one (scale, image) contiguous, whatever the dispatch order
     const unsigned item = (unsigned)(((scale * a.B + b) * a.nchunks + chunk) * a.nstrips + strip);
