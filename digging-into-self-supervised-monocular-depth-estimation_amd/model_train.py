@@ -64,8 +64,10 @@ class graphed_step(object):
         for g in opt.param_groups:
             g["capturable"] = True
             g["lr"] = self.lr
-        wanted = tr.compute._step_reads
+        # the velodyne ground truth is read by control.metric from the batch itself, never by the captured step
+        wanted = lambda k: tr.compute._step_reads(k) and not (isinstance(k, tuple) and k[0] == "depth")  # noqa: E731
         self.static = {k: (v.to(dev).clone() if torch.is_tensor(v) and wanted(k) else v) for k, v in example.items()}
+        self.copied = {k for k, v in example.items() if torch.is_tensor(v) and wanted(k)}
         from model_layer.depth_encoder import BatchNorm2d
         self.bns = [m for net in tr.setting.raw_model.values() for m in net.modules() if isinstance(m, BatchNorm2d)]
         side = torch.cuda.Stream(dev)
@@ -89,7 +91,7 @@ class graphed_step(object):
 
     def __call__(self, inputs):
         for k, v in inputs.items():
-            if torch.is_tensor(v) and k in self.static and torch.is_tensor(self.static[k]):
+            if k in self.copied and torch.is_tensor(v):
                 self.static[k].copy_(v, non_blocking=True)
         self.graph.replay()
         for m, inc in zip(self.bns, self.bn_incr):
