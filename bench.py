@@ -174,6 +174,71 @@ def cpu_baseline(batch=4, steps=10):
     return out
 
 
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_bench_kernel_pmc.json")   # written by tools/pmc_bench.sh
+
+
+def roofline_blocks(args, opt, frame_ids, tsum):
+    """`roofline` (+ `roofline_other`) of the JSON line from the HIP-event timings of the timed steps' own launches."""
+    from mdx import functional as F   # noqa: F401
+    nS = len(frame_ids) - 1
+    nsc = len(opt.scales)
+    per_scale = {n: sum(alg_bytes(args.batch, opt.height, opt.width, nS, sc, bwd=(n == "bwd"))
+                        for sc in range(nsc)) for n in ("fwd", "bwd")}
+    k = {}
+    if tsum.get("train", (0, 0))[1]:
+        k["train"] = {"ms": 1e-3 * tsum["train"][0], "launches": tsum["train"][1],
+                      "bytes": float(per_scale["fwd"] + per_scale["bwd"]),
+                      "name": "mdx::photometric_train_kernel<%d>" % nS}
+    for n, kn in (("fwd", "mdx::photometric_fwd_coef_kernel<%d>"), ("bwd", "mdx::photometric_bwd_coef_kernel<%d>")):
+        if tsum.get(n, (0, 0))[1]:
+            k[n] = {"ms": 1e-3 * tsum[n][0], "launches": tsum[n][1], "bytes": per_scale[n] / float(nsc),
+                    "name": kn % nS}
+    if not k:
+        return {}
+    for n in k:
+        k[n]["GBs"] = k[n]["bytes"] / (k[n]["ms"] * 1e-3) / 1e9
+    dom = max(k, key=lambda n: k[n]["ms"] * k[n]["launches"])
+    # Counters of the committed rocprofv3 --pmc passes over THIS command's own launches (tools/pmc_bench.sh profiles
+    # `python bench.py` with --kernel-include-regex on the photometric kernels: same tensors as the timed steps).  They
+    # describe one build of the library: tied to it by the hash of libmdx_hip.so and to the workload by its shape;
+    # anything else reports null rather than a stale number.
+    traffic = issue = None
+    try:
+        import hashlib
+        pmc = json.load(open(PMC_FILE))
+        from mdx import LIB_PATH
+        so = hashlib.sha256(open(LIB_PATH, "rb").read()).hexdigest()[:16]
+        ent = next((v for kk, v in pmc["kernels"].items() if kk.startswith(k[dom]["name"].split("<")[0])
+                    and ("<%d" % nS) in kk), None)
+        same_shape = pmc.get("shape") == [args.batch, opt.height, opt.width, nS, nsc]
+        if ent and same_shape and pmc.get("lib_sha16") == so:
+            traffic = ent.get("traffic_bytes")
+            issue = {kk: ent[kk] for kk in ("valu_wave_insts", "valu_issue_us", "wait_any_frac", "wait_inst_frac",
+                                            "active_frac", "kernel_us_profiled", "vgprs", "waves_per_simd") if kk in ent}
+            issue["source"] = pmc.get("source")
+    except (OSError, ValueError, KeyError):
+        pass
+    launch_us = 1e3 * k[dom]["ms"]
+    # VALU-issue roofline of the same launch: wave-instructions x 2 cycles / (1024 SIMDs x 2.4 GHz) over its duration
+    valu_frac = (issue["valu_issue_us"] / launch_us) if issue and issue.get("valu_issue_us") else None
+    hbm_frac = k[dom]["GBs"] / HBM_PEAK_GBS
+    out = {"roofline": {"kernel": k[dom]["name"],
+                        "bound": "hbm",        # the roofline `frac` is quoted against (BASELINE.json: HBM roofline of this kernel)
+                        "limiter": (None if valu_frac is None else ("valu-issue" if valu_frac > hbm_frac else "hbm")),
+                        "achieved": k[dom]["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": hbm_frac, "valu_issue_frac": valu_frac, "traffic": traffic, "issue": issue,
+                        "launch_us": launch_us, "alg_bytes_per_launch": k[dom]["bytes"],
+                        "launches_timed": k[dom]["launches"],
+                        "alg_bytes": "SURVEY 8d per scale (fwd: B*H*W*(12+12S+1)+B*h*w*4, bwd: ...+B*h*w*8), summed "
+                                     "over the %d scale(s) x {fwd,bwd} one launch covers" % (nsc if dom == "train" else 1),
+                        "timing": "HIP events recorded by the library around this kernel in the timed steps"}}
+    others = [n for n in k if n != dom]
+    if others:
+        out["roofline_other"] = [{"kernel": k[n]["name"], "achieved": k[n]["GBs"], "frac": k[n]["GBs"] / HBM_PEAK_GBS,
+                                  "launch_us": 1e3 * k[n]["ms"], "alg_bytes_per_launch": k[n]["bytes"]} for n in others]
+    return out
+
+
 def free_port():
     import socket
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
@@ -227,7 +292,9 @@ def trainer_loop(args, frame_ids, steps, warmup, workers, raw):
     opt = make_opt(args.batch, height=args.height, width=args.width, frame_ids=frame_ids, num_layers=args.num_layers,
                    amp=args.amp, workers=workers)
     opt.fused_train = not args.per_scale_kernels
-    opt.synthetic_length = (steps + warmup + 4) * args.batch * int(os.environ.get("WORLD_SIZE", "1"))
+    opt.grad_comm, opt.bucket_mb = args.grad_comm, args.bucket_mb
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    opt.synthetic_length = (steps + warmup + 4) * args.batch * world
     opt.synthetic_pool = 4 * args.batch          # the stand-in dataset must not be what is measured
     opt.uint8_loader = not args.float_loader     # colours uint8 through the host pipeline, x/255 on the GPU
     opt.collate_step_keys = not args.float_loader
@@ -253,7 +320,13 @@ def trainer_loop(args, frame_ids, steps, warmup, workers, raw):
         log = tr.control.metric(b, tr.train_step(b), log)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    vals = {k: tr.control._mean(v) for k, v in log.items()}
+    if torch.distributed.is_initialized():
+        tmax = torch.tensor([dt], device=tr.device if tr.setting.sync.backend == "nccl" else "cpu", dtype=torch.float64)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax[0])
+    vals = tr.control.epoch_means(log)
+    graphed = tr._graphed is not None
+    exchange = None if tr.setting.sync is None else {"buckets": len(tr.setting.sync.buckets), "in_graph": graphed}
     del it, b
     # the persistent loader workers and the captured graph of this trainer must not outlive the measurement
     import gc
@@ -262,32 +335,40 @@ def trainer_loop(args, frame_ids, steps, warmup, workers, raw):
     del tr
     gc.collect()
     torch.cuda.synchronize()
-    return {"value": args.batch * steps / dt, "unit": "images/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
-            "workers": workers, "uint8_loader": bool(opt.uint8_loader), "hip_graph": bool(opt.graph),
+    return {"value": world * args.batch * steps / dt, "unit": "images/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
+            "n_gpus": world, "gradient_exchange": exchange,
+            "workers": workers, "uint8_loader": bool(opt.uint8_loader), "hip_graph": graphed,
             "raw_frames": raw, "what": "model_train.trainer: DataLoader (" + ("decoded 1242x375 frames, Lanczos pyramid / jitter / ToTensor on the GPU, " if raw else "prepared uint8 entries, ") + "pinned, side-stream upload) -> train_step -> control.metric every step", "abs_rel_monitor": vals.get("abs_rel")}
 
 
-def trainer_loop_child(feed):
-    """`python bench.py --trainer-loop-child raw|prepared <same shape arguments>` in a fresh process; its one JSON line."""
+def trainer_loop_child(feed, port_offset=1):
+    """`python bench.py --trainer-loop-child raw|prepared <same shape arguments>` in a fresh process; its one JSON line.
+    In a multi-rank job every rank starts its own child (never a re-exec) and the children form a job of their own on
+    the next rendezvous port: the loop is measured with the gradient exchange in it."""
     import subprocess
     keep = [a for a in sys.argv[1:] if a not in ("--one-loop",)]
     cmd = [sys.executable, os.path.abspath(__file__), "--trainer-loop-child", feed] + keep
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        env["MASTER_PORT"] = str(int(os.environ["MASTER_PORT"]) + port_offset)
+    else:
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
     try:
-        out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     except subprocess.TimeoutExpired:
         return {"error": "trainer-loop child timed out"}
     lines = [ln for ln in out.stdout.decode().splitlines() if ln.startswith("{")]
-    if out.returncode != 0 or not lines:
-        return {"error": "trainer-loop child failed (rc %d): %s" % (out.returncode, out.stderr.decode()[-400:])}
-    return json.loads(lines[-1])
+    if out.returncode != 0 or (not lines and int(os.environ.get("RANK", "0")) == 0):
+        return {"error": "trainer-loop child failed (rc %d): %s" % (out.returncode, out.stderr.decode()[-600:])}
+    return json.loads(lines[-1]) if lines else {}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=100)      # SURVEY 8d: >= 100 timed steps ...
+    ap.add_argument("--warmup", type=int, default=20)      # ... after 20 warm-up steps (2.5 s in all at configs[1])
     ap.add_argument("--batch", type=int, default=12)
     ap.add_argument("--amp", type=str, default="none", choices=["none", "bf16"])
     ap.add_argument("--height", type=int, default=192)
@@ -298,7 +379,14 @@ def main():
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark (MIOpen find mode)")
     ap.add_argument("--no-miopen-db", action="store_true", help="ignore the shipped gfx950 find-db (MIOpen heuristics)")
     ap.add_argument("--graph", action="store_true",
-                    help="capture the whole step (nets + fused loss + Adam) into ONE hipGraph and replay it (1 GPU)")
+                    help="capture the whole step (nets + fused loss + gradient all-reduce + Adam) into ONE hipGraph and "
+                         "replay it -- any number of ranks")
+    ap.add_argument("--dist", action="store_true",
+                    help="with --gpus 1: run the data-parallel path anyway (a process group of ONE rank over RCCL: flat "
+                         "gradient buffer, bucketed all-reduce issued inside backward)")
+    ap.add_argument("--bucket-mb", type=int, default=0,
+                    help="size of a gradient all-reduce bucket (0 = one bucket for a captured step, 32 MB eager)")
+    ap.add_argument("--grad-comm", type=str, default="fp32", choices=["fp32", "bf16"], help="dtype of the gradient all-reduce")
     ap.add_argument("--per-scale-kernels", action="store_true",
                     help="round-1 path: one fused forward + one backward kernel per scale instead of the one-launch "
                          "training kernel")
@@ -310,7 +398,9 @@ def main():
                     help="trainer loop without the hipGraph replay of the step (model_option --graph 0)")
     ap.add_argument("--one-loop", action="store_true",
                     help="trainer loop only with decoded frames (skip the second run fed with ready 192x640 entries)")
-    ap.add_argument("--workers", type=int, default=12, help="DataLoader workers of the trainer-loop measurement")
+    ap.add_argument("--workers", type=int, default=0,
+                    help="DataLoader workers of the trainer-loop measurement (0 = sized from the host share of this rank: "
+                         "12 for fp32, 16 with --amp bf16 whose step consumes ~900 samples/s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--selftest-launcher", action="store_true", help=argparse.SUPPRESS)
@@ -332,72 +422,68 @@ def main():
     local = local % torch.cuda.device_count()          # rehearsal: several ranks may share one GPU
     torch.cuda.set_device(local)
     device = "cuda:%d" % local
-    if world > 1:
-        backend = os.environ.get("MDX_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm; "gloo" only to rehearse
+    if args.workers <= 0:
+        share = max(2, len(os.sched_getaffinity(0)) // max(1, min(world, torch.cuda.device_count())))
+        args.workers = max(2, min(16 if args.amp == "bf16" else 12, share - 2))
+    backend = os.environ.get("MDX_DIST_BACKEND", "nccl")       # "nccl" is RCCL on ROCm; "gloo" only to rehearse
+    if world > 1 or args.dist:
+        kw = {}
+        if world == 1:
+            kw = {"init_method": "tcp://127.0.0.1:%d" % free_port(), "rank": 0, "world_size": 1}
         if backend == "nccl":
-            torch.distributed.init_process_group("nccl", device_id=torch.device(device))
+            torch.distributed.init_process_group("nccl", device_id=torch.device(device), **kw)
         else:
-            torch.distributed.init_process_group(backend)
+            torch.distributed.init_process_group(backend, **kw)
+    distributed = torch.distributed.is_initialized()
     pkg = importlib.import_module("digging-into-self-supervised-monocular-depth-estimation_amd")
     miopen_db = None if args.no_miopen_db else pkg.install_miopen_db(rank)   # tuned conv solvers (gfx950 find-db)
-    from model_tool import setting, compute
 
     torch.manual_seed(1234 + rank)
     frame_ids = [t if t == "s" else int(t) for t in args.frame_ids.split()]
     if args.trainer_loop_child:
-        print(json.dumps(trainer_loop(args, frame_ids, args.steps, args.warmup, args.workers, args.trainer_loop_child == "raw")))
+        res = trainer_loop(args, frame_ids, args.steps, args.warmup, args.workers, args.trainer_loop_child == "raw")
+        if rank == 0:
+            print(json.dumps(res))
+        if distributed:
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
         return
+    from model_train import trainer, graphed_step
     opt = make_opt(args.batch, height=args.height, width=args.width, frame_ids=frame_ids, num_layers=args.num_layers,
                    amp=args.amp)
     opt.channels_last = args.channels_last
     opt.fused_train = not args.per_scale_kernels
+    opt.grad_comm, opt.bucket_mb = args.grad_comm, args.bucket_mb
     # MIOpen picks the tuned solvers from the shipped find-db in immediate mode already (fp32: same images/s as find
     # mode).  Find mode proper (--miopen-find) returns at once on a db hit but searches for minutes on a miss, so it
     # is never on by default; bf16 networks gain from it (a few more solvers are only reachable through find).
-    torch.backends.cudnn.benchmark = args.miopen_find
-    st = setting(opt, device)
-    cp = compute(opt, device)
+    opt.miopen_find, opt.graph = args.miopen_find, args.graph
+    # the product's own step (model_train.trainer._eager_step / graphed_step) on one batch that stays resident in HBM
+    tr = trainer(opt)
+    st, cp = tr.setting, tr.compute
     st.set_train()
     inputs = one_batch(st, device)
-    optim = st.optim["optimizer"]
 
     def step():
-        outputs = {}
-        i, o = cp.forward_depth(inputs, outputs, st)
-        i, o = cp.forward_pose(i, o, st)
-        i, o = cp.image2warping(i, o, st)
-        o = cp.compute_loss(i, o, st)
-        optim.zero_grad(set_to_none=True)
-        o["loss"].backward()
-        optim.step()
-        return o["loss"]
+        return tr._eager_step(inputs)["loss"]
 
     def fence():
-        if world > 1:
+        if distributed:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
     graph = None
-    if args.graph and world == 1:
-        # hipGraph: warm up on a side stream (MIOpen picks its kernels, the allocator settles), capture one step,
+    if args.graph:
+        if not tr.can_graph():
+            raise SystemExit("bench.py: --graph needs a capturable step (device-side noise, RCCL process group)")
+        # hipGraph: side-effect-free warm-up on a side stream, capture of one step (the gradient exchange included),
         # then every timed step is a single graph launch -- ~1600 kernel launches leave the host's critical path
-        for g in optim.param_groups:
-            g["capturable"] = True
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(max(args.warmup, 3)):
-                step()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            static_loss = step()
-        torch.cuda.synchronize()
+        graph = graphed_step(tr, inputs)
+        for _ in range(args.warmup):
+            graph({})
 
         def run():
-            graph.replay()
-            return static_loss
+            return graph({})["loss"]             # inputs stay where they are: replay only
     else:
         run = step
         for _ in range(args.warmup):
@@ -414,17 +500,18 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     F.TIMING = None
-    if rank == 0 and not args.no_roofline and graph is not None:
+    if not args.no_roofline and graph is not None:
         # graph replay launches no Python: time the kernels over a few eager steps after the timed region instead
+        # (every rank: the eager step contains the exchange)
         timing = {"fwd": [], "bwd": [], "train": []}
-        F.TIMING = timing
+        F.TIMING = timing if rank == 0 else None
         for _ in range(5):
             step()
         torch.cuda.synchronize()
         F.TIMING = None
     ranks_verified = 1
-    if world > 1:
-        tdev = device if os.environ.get("MDX_DIST_BACKEND", "nccl") == "nccl" else "cpu"
+    if distributed:
+        tdev = device if backend == "nccl" else "cpu"
         tmax = torch.tensor([dt], device=tdev, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax[0])
@@ -432,7 +519,9 @@ def main():
         torch.distributed.all_reduce(ones)           # every rank really took part (RCCL when backend is nccl)
         ranks_verified = int(ones[0])
     loss_val = float(loss.detach())
+    failed = False
 
+    line = None
     if rank == 0:
         line = {
             "metric": "images/sec training, KITTI %dx%d batch %d/GPU" % (args.height, args.width, args.batch), "value": world * args.batch * args.steps / dt,
@@ -448,68 +537,34 @@ def main():
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world},
             "ranks_verified": ranks_verified, "final_loss": loss_val, "hip_graph": bool(graph is not None), "miopen_find_db": bool(miopen_db),
         }
+        if st.sync is not None:
+            line["gradient_exchange"] = {"backend": "rccl" if st.sync.backend == "nccl" else st.sync.backend,
+                                         "buckets": len(st.sync.buckets), "bytes": 4 * st.sync.flat.numel(),
+                                         "comm_dtype": args.grad_comm, "in_graph": bool(graph is not None),
+                                         "what": "flat gradient buffer; bucketed all-reduce(mean) issued from inside backward"}
         if not args.no_roofline and timing is not None:
-            tsum = F.timing_summary(timing)
-            nS = len(frame_ids) - 1
-            nsc = len(opt.scales)
-            per_scale = {n: sum(alg_bytes(args.batch, opt.height, opt.width, nS, sc, bwd=(n == "bwd"))
-                                for sc in range(nsc)) for n in ("fwd", "bwd")}
-            k = {}
-            if tsum.get("train", (0, 0))[1]:
-                k["train"] = {"ms": 1e-3 * tsum["train"][0], "launches": tsum["train"][1],
-                              "bytes": float(per_scale["fwd"] + per_scale["bwd"]),
-                              "name": "mdx::photometric_train_kernel<%d>" % nS}
-            for n, kn in (("fwd", "mdx::photometric_fwd_coef_kernel<%d>"), ("bwd", "mdx::photometric_bwd_coef_kernel<%d>")):
-                if tsum.get(n, (0, 0))[1]:
-                    k[n] = {"ms": 1e-3 * tsum[n][0], "launches": tsum[n][1], "bytes": per_scale[n] / float(nsc),
-                            "name": kn % nS}
-            for n in k:
-                k[n]["GBs"] = k[n]["bytes"] / (k[n]["ms"] * 1e-3) / 1e9
-            dom = max(k, key=lambda n: k[n]["ms"] * k[n]["launches"])
-            # Counters of the committed rocprofv3 --pmc passes (tools/pmc_train.sh on tools/kbench.py's data, same
-            # shape).  They describe one build of the library: tied to it by the hash of libmdx_hip.so and to the
-            # workload by its shape; anything else reports null rather than a stale number.
-            traffic = issue = None
-            try:
-                import hashlib
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_train_kernel_pmc.json")))
-                from mdx import LIB_PATH
-                so = hashlib.sha256(open(LIB_PATH, "rb").read()).hexdigest()[:16]
-                ent = pmc["kernels"].get(k[dom]["name"])
-                same_shape = pmc.get("shape") == [args.batch, opt.height, opt.width, nS, nsc]
-                if ent and same_shape and pmc.get("lib_sha16") == so:
-                    traffic = ent.get("traffic_bytes")
-                    issue = {kk: ent[kk] for kk in ("valu_wave_insts", "valu_issue_us", "wait_any_frac",
-                                                    "wait_inst_frac", "active_frac") if kk in ent}
-            except (OSError, ValueError, KeyError):
-                pass
-            bound = "valu-issue" if (issue and issue.get("valu_issue_us", 0) > 0.3 * 1e3 * k[dom]["ms"]) else "hbm"
-            line["roofline"] = {"kernel": k[dom]["name"], "bound": bound if issue else "hbm (issue counters not available for this build)",
-                                "achieved": k[dom]["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": k[dom]["GBs"] / HBM_PEAK_GBS, "traffic": traffic, "issue": issue,
-                                "launch_us": 1e3 * k[dom]["ms"], "alg_bytes_per_launch": k[dom]["bytes"],
-                                "launches_timed": k[dom]["launches"],
-                                "alg_bytes": "SURVEY 8d per scale (fwd: B*H*W*(12+12S+1)+B*h*w*4, bwd: ...+B*h*w*8), summed "
-                                             "over the %d scale(s) x {fwd,bwd} one launch covers" % (nsc if dom == "train" else 1),
-                                "timing": "HIP events recorded by the library around this kernel in the timed steps"}
-            others = [n for n in k if n != dom]
-            if others:
-                line["roofline_other"] = [{"kernel": k[n]["name"], "achieved": k[n]["GBs"], "frac": k[n]["GBs"] / HBM_PEAK_GBS,
-                                           "launch_us": 1e3 * k[n]["ms"], "alg_bytes_per_launch": k[n]["bytes"]}
-                                          for n in others]
-        if not args.no_trainer_loop and world == 1 and graph is None:
-            del st, cp, inputs, optim
-            torch.cuda.empty_cache()
-            # twice, each in its own child process (a second loop in the same process inherits the first one's loader
-            # workers and allocator state and measured 5 % low): fed with decoded 1242x375 frames (the data path of a
-            # real run: pyramid / jitter / ToTensor are extra GPU work the resident figure does not contain) and with
-            # ready entries (the loop alone)
-            for key, feed in (("trainer_loop", "raw"), ("trainer_loop_prepared_frames", "prepared")):
-                if key != "trainer_loop" and args.one_loop:
-                    continue
-                line[key] = trainer_loop_child(feed)
-                if "value" in line[key]:
-                    line[key]["vs_resident"] = line[key]["value"] / line["value"]
+            line.update(roofline_blocks(args, opt, frame_ids, F.timing_summary(timing)))
+    if not args.no_trainer_loop and (graph is None or distributed):
+        graph = None
+        del tr, st, cp, inputs
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        # twice, each in its own child process per rank (a second loop in the same process inherits the first one's
+        # loader workers and allocator state and measured 5 % low): fed with decoded 1242x375 frames (the data path of
+        # a real run: pyramid / jitter / ToTensor are extra GPU work the resident figure does not contain) and with
+        # ready entries (the loop alone)
+        for k, (key, feed) in enumerate((("trainer_loop", "raw"), ("trainer_loop_prepared_frames", "prepared"))):
+            if key != "trainer_loop" and args.one_loop:
+                continue
+            res = trainer_loop_child(feed, port_offset=k + 1)
+            failed = failed or "error" in res
+            if rank == 0:
+                line[key] = res
+                if "value" in res:
+                    res["vs_resident"] = res["value"] / line["value"]
+    if rank == 0:
+        if not args.no_trainer_loop and world == 1:
             # the data layer's share: host cost per sample with and without the GPU image preparation
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -519,9 +574,11 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))
-    if world > 1:
+    if distributed:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    if failed:
+        raise SystemExit(4)       # a measurement this line promises did not run
 
 
 if __name__ == "__main__":

@@ -204,11 +204,35 @@ static __device__ __forceinline__ void swait12(SRows &m, float *o)     // the lo
     o[8] = m.c.x; o[9] = m.c.y; o[10] = m.c.z; o[11] = m.c.w;
 }
 
-template <int S>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S <= 2 ? 3 : 2, S <= 2 ? 3 : 2))) void photometric_train_kernel(TrainArgs a)
+// SSIM value alone (the no-gradient form of the kernel): ssim_raw()'s operation order, bit-equal to ssim_both().val
+MDX_DEV float ssim_val(const SsimTerms &s, const TargetStats &t)
+{
+    const float mxx = s.mu_x * s.mu_x;
+    const float mxy = s.mu_x * t.mu;
+    const float sig_x = s.ex2 - mxx;
+    const float sig_y = t.e2 - t.mu2;
+    const float sig_xy = s.exy - mxy;
+    float a = 2.0f * s.mu_x;
+    a = a * t.mu;
+    const float A1 = a + MDX_C1;
+    float A2 = 2.0f * sig_xy;
+    A2 = A2 + MDX_C2;
+    const float n = A1 * A2;
+    const float B1 = (mxx + t.mu2) + MDX_C1;
+    const float B2 = (sig_x + sig_y) + MDX_C2;
+    const float d = B1 * B2;
+    const float q = n / d;
+    return clamp01((1.0f - q) / 2.0f);
+}
+
+// GRAD = true: the training form (loss, indices AND the unit-upstream gradients).  GRAD = false: validation /
+// torch.no_grad() (model_train.py:75-79 runs the loss on the validation split every epoch): the same marching wave
+// without the coefficient histories, the stash and the gradient phase -- every scale's forward in ONE launch.
+template <int S, bool GRAD>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <= 2 ? 3 : 2) : (S <= 3 ? 4 : 3), GRAD ? (S <= 2 ? 3 : 2) : 8))) void photometric_train_kernel(TrainArgs a)
 {
     // per-lane stash ring: [row slot][2f] = (d colour_c / du, u), [2f+1] = (d colour_c / dv, v) of frame f
-    __shared__ float4 s_stash[3][2 * S][64];
+    __shared__ float4 s_stash[GRAD ? 3 : 1][GRAD ? 2 * S : 1][GRAD ? 64 : 1];
 
     const int lane = threadIdx.x;
     // ---- work item: level-major order (see TrainArgs), dispatched in block order.  An XCD-contiguous order inside each
@@ -362,8 +386,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S <= 2 ? 3 :
             pf_nz[f] = at32(noise_s + ((size_t)b * S + f) * HW, po);
         }
     };
-    prefetch_warp_row(r0 - 2);
-    prefetch_ssim_row(r0 - 3);
+    prefetch_warp_row(r0 - (GRAD ? 2 : 1));
+    prefetch_ssim_row(r0 - (GRAD ? 3 : 2));
     // The gradient row of a step is stored in the NEXT step, behind that step's load issue: the memory counter wait
     // at the top of a step (everything outstanding, the loop edge makes it conservative) would otherwise sit right
     // behind a store that has only just been issued.
@@ -375,10 +399,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S <= 2 ? 3 :
     unsigned long long st_last = __builtin_amdgcn_s_memtime();
     const unsigned long long st_begin = st_last;
 #endif
-    const int nsteps = (r1 - r0) + 4;
+    // without the gradient phase a chunk needs one halo row each side (SSIM of rows r0 .. r1-1) instead of two
+    const int nsteps = (r1 - r0) + (GRAD ? 4 : 2);
 #pragma unroll 1
     for (int t = 0; t < nsteps; ++t) {
-        const int wr = r0 - 2 + t;        // row warped in this step
+        const int wr = r0 - (GRAD ? 2 : 1) + t;        // row warped in this step
         const int sr = wr - 1;            // row whose SSIM / arg-min / coefficients are formed
         const int gr = wr - 2;            // row whose gradient is formed
         const int slot_w = t % 3, slot_r = (t + 1) % 3;
@@ -438,8 +463,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S <= 2 ? 3 :
                 for (int c = 0; c < 3; ++c)
                     cn[f][c] = load_corners(a.src.img[f] + ((size_t)b * 3 + c) * HW, H, W, tp[f]);
             prefetch_warp_row(wr + 1);
-            if (gup_row >= 0 && out_lane) at32(gup_s + (size_t)b * HW, (unsigned)(gup_row * W + pxr)) = gup_val;
-            gup_row = -1;
+            if constexpr (GRAD) {
+                if (gup_row >= 0 && out_lane) at32(gup_s + (size_t)b * HW, (unsigned)(gup_row * W + pxr)) = gup_val;
+                gup_row = -1;
+            }
             MDX_STAMP(0);   // geometry, taps, load issue
             int fl = 0;
 #pragma unroll
@@ -450,24 +477,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S <= 2 ? 3 :
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     xh[2][f][c] = sample(cn[f][c], tp[f]);
-                    du[c] = (cn[f][c].ne - cn[f][c].nw) * dy1 + (cn[f][c].se - cn[f][c].sw) * dy0;
-                    dv[c] = (cn[f][c].sw - cn[f][c].nw) * dx1 + (cn[f][c].se - cn[f][c].ne) * dx0;
+                    if constexpr (GRAD) {
+                        du[c] = (cn[f][c].ne - cn[f][c].nw) * dy1 + (cn[f][c].se - cn[f][c].sw) * dy0;
+                        dv[c] = (cn[f][c].sw - cn[f][c].nw) * dx1 + (cn[f][c].se - cn[f][c].ne) * dx0;
+                    }
                 }
-                s_stash[slot_w][2 * f][lane] = make_float4(du[0], du[1], du[2], pr[f].u);
-                s_stash[slot_w][2 * f + 1][lane] = make_float4(dv[0], dv[1], dv[2], pr[f].v);
-                fl |= (tp[f].inx ? 1 : 0) << (2 * f);
-                fl |= (tp[f].iny ? 1 : 0) << (2 * f + 1);
+                if constexpr (GRAD) {
+                    s_stash[slot_w][2 * f][lane] = make_float4(du[0], du[1], du[2], pr[f].u);
+                    s_stash[slot_w][2 * f + 1][lane] = make_float4(dv[0], dv[1], dv[2], pr[f].v);
+                    fl |= (tp[f].inx ? 1 : 0) << (2 * f);
+                    fl |= (tp[f].iny ? 1 : 0) << (2 * f + 1);
+                }
             }
             flp |= fl << 16;
             MDX_STAMP(1);   // corner data arrives, samples, derivatives, stash
         }
 
         // ================= (2) SSIM + L1, min / arg-min, coefficient triplets of row sr =================
-        selp = (unsigned)selp >> 4;
+        if constexpr (GRAD) {
+            selp = (unsigned)selp >> 4;
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
+            for (int c = 0; c < 3; ++c)
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { ch[0][c][k] = ch[1][c][k]; ch[1][c][k] = ch[2][c][k]; }
+                for (int k = 0; k < 3; ++k) { ch[0][c][k] = ch[1][c][k]; ch[1][c][k] = ch[2][c][k]; }
+        }
         if (t >= 2 && sr >= 0 && sr < H) {
             // every product a pool reads through DPP is formed in a block of its own, pinned ahead of the pools by a
             // scheduling barrier (see pool3_n); three chains at a time keep the transient registers low
@@ -512,20 +545,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S <= 2 ? 3 :
                     pool3_n<3>(q, o);
                     SsimTerms st;
                     st.mu_x = o[0]; st.ex2 = o[1]; st.exy = o[2];
-                    const SsimBoth sb = ssim_both(st, ts[c], 0.85f / 3.0f);
-                    ss[c] = sb.val;
-                    sg[c] = sb.g;
+                    if constexpr (GRAD) {
+                        const SsimBoth sb = ssim_both(st, ts[c], 0.85f / 3.0f);
+                        ss[c] = sb.val;
+                        sg[c] = sb.g;
+                    } else {
+                        ss[c] = ssim_val(st, ts[c]);
+                    }
                     ad[c] = fabsf(yh[1][c] - xh[1][f][c]);
                 }
                 const float rl = reprojection_combine(ss, ad);
                 const bool better = f == 0 || rl < best_r;
                 best_r = better ? rl : best_r;
                 fr = better ? f : fr;
+                if constexpr (GRAD) {
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    cand[c][0] = better ? sg[c].alpha : cand[c][0];
-                    cand[c][1] = better ? sg[c].beta : cand[c][1];
-                    cand[c][2] = better ? sg[c].gamma : cand[c][2];
+                    for (int c = 0; c < 3; ++c) {
+                        cand[c][0] = better ? sg[c].alpha : cand[c][0];
+                        cand[c][1] = better ? sg[c].beta : cand[c][1];
+                        cand[c][2] = better ? sg[c].gamma : cand[c][2];
+                    }
                 }
             }
             // concat [ident + 1e-5*noise, reproj] and torch.min's first-minimum rule (processor.py:194-204)
@@ -545,20 +584,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S <= 2 ? 3 :
                 bi = reproj_wins ? S + fr : fi;
                 fr = reproj_wins ? fr : -1;
             }
-            if (!ssim_lane) fr = -1;
-            const bool keep = fr >= 0;
+            if constexpr (GRAD) {
+                if (!ssim_lane) fr = -1;
+                const bool keep = fr >= 0;
 #pragma unroll
-            for (int c = 0; c < 3; ++c)
+                for (int c = 0; c < 3; ++c)
 #pragma unroll
-                for (int k = 0; k < 3; ++k) ch[2][c][k] = keep ? cand[c][k] : 0.f;
-            selp |= (fr + 1) << 8;
+                    for (int k = 0; k < 3; ++k) ch[2][c][k] = keep ? cand[c][k] : 0.f;
+                selp |= (fr + 1) << 8;
+            }
             if (out_lane && sr >= r0 && sr < r1) {
                 const unsigned po = (unsigned)(sr * W + pxr);
                 at32(idx_s + (size_t)b * HW, po) = (uint8_t)bi;
                 if (to_opt_s) at32(to_opt_s + (size_t)b * HW, po) = best;
                 acc += (double)best;
             }
-        } else {
+        } else if constexpr (GRAD) {
 #pragma unroll
             for (int c = 0; c < 3; ++c)
 #pragma unroll
@@ -568,7 +609,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S <= 2 ? 3 :
 
         MDX_STAMP(2);   // SSIM phase
         // ================= (3) gradient of row gr =================
-        if (t < 4) continue;
+        if constexpr (GRAD) {
+        if (t >= 4) {
         const float wy0 = gr == 1 ? 2.f : 1.f, wy2 = gr == H - 2 ? 2.f : 1.f;   // reflection-pad fold (y)
 #if MDX_TRAIN_SLOAD
         float iK[12], Pm[S][12];
@@ -654,8 +696,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S <= 2 ? 3 :
         gup_val = gdepth * (-d.disp_b * depth * depth);
         gup_row = gr;
         MDX_STAMP(3);   // gradient phase
+        }
+        }
     }
-    if (gup_row >= 0 && out_lane) at32(gup_s + (size_t)b * HW, (unsigned)(gup_row * W + pxr)) = gup_val;
+    if constexpr (GRAD)
+        if (gup_row >= 0 && out_lane) at32(gup_s + (size_t)b * HW, (unsigned)(gup_row * W + pxr)) = gup_val;
 #ifdef MDX_TRAIN_STAMPS
     if (lane == 0 && a.stamps) {
 #pragma unroll
@@ -670,6 +715,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S <= 2 ? 3 :
 
     // ---- per-item partials: d(P) (register reduction, total in lane 63) and the loss sum ----
     // d(P)[i][j] = sum gq_i * depth * r_j,  r_j = k_j0*px + k_j1*py + k_j2  (j < 3);  d(P)[i][3] = sum gq_i
+    if constexpr (GRAD)
 #pragma unroll
     for (int f = 0; f < S; ++f)
 #pragma unroll
@@ -976,7 +1022,9 @@ MDX_EXPORT int mdx_photometric_train(const mdx_train_desc *d, const float *const
 {
     int rc = validate_train(d);
     if (rc) return rc;
-    if (!disp || !target || !src || !invK || !P || !idx || !loss_sum || !gdisp || !gP) return MDX_ERR_NULL_POINTER;
+    if (!disp || !target || !src || !invK || !P || !idx || !loss_sum) return MDX_ERR_NULL_POINTER;
+    if ((gdisp == nullptr) != (gP == nullptr)) return MDX_ERR_NULL_POINTER;
+    const bool grad = gdisp != nullptr;      // both null: every scale's forward alone (validation, torch.no_grad())
     const bool automask = (d->flags & MDX_FLAG_AUTOMASK) != 0;
     if (automask && (!ident || !noise)) return MDX_ERR_NULL_POINTER;
     for (int f = 0; f < d->S; ++f)
@@ -999,12 +1047,12 @@ MDX_EXPORT int mdx_photometric_train(const mdx_train_desc *d, const float *const
     float *gup_ws = (float *)((char *)workspace + p.off_gup);
     const size_t n = (size_t)d->B * d->H * d->W;
     for (int s = 0; s < d->nscales; ++s) {
-        if (!disp[s] || !P[s] || !idx[s] || !gdisp[s] || (automask && !noise[s])) return MDX_ERR_NULL_POINTER;
+        if (!disp[s] || !P[s] || !idx[s] || (grad && !gdisp[s]) || (automask && !noise[s])) return MDX_ERR_NULL_POINTER;
         a.h[s] = d->h[s]; a.w[s] = d->w[s];
         a.disp[s] = disp[s]; a.P[s] = P[s]; a.noise[s] = automask ? noise[s] : nullptr; a.idx[s] = idx[s];
         a.to_opt[s] = to_opt ? to_opt[s] : nullptr;
         const bool same = d->h[s] == d->H && d->w[s] == d->W;
-        a.gup[s] = same ? gdisp[s] : gup_ws + s * n;
+        a.gup[s] = !grad ? nullptr : (same ? gdisp[s] : gup_ws + s * n);
     }
     for (int s = d->nscales; s < MDX_MAX_SCALES; ++s) {   // never selected; keep the picks well defined
         a.h[s] = a.h[0]; a.w[s] = a.w[0]; a.disp[s] = a.disp[0]; a.P[s] = a.P[0]; a.noise[s] = a.noise[0];
@@ -1016,26 +1064,30 @@ MDX_EXPORT int mdx_photometric_train(const mdx_train_desc *d, const float *const
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)p.items), block(64);
     if (t && t->start) (void)hipEventRecord((hipEvent_t)t->start, st);
-    switch (d->S) {
-    case 1: hipLaunchKernelGGL((photometric_train_kernel<1>), grid, block, 0, st, a); break;
-    case 2: hipLaunchKernelGGL((photometric_train_kernel<2>), grid, block, 0, st, a); break;
-    case 3: hipLaunchKernelGGL((photometric_train_kernel<3>), grid, block, 0, st, a); break;
-    case 4: hipLaunchKernelGGL((photometric_train_kernel<4>), grid, block, 0, st, a); break;
+    switch (d->S * 2 + (grad ? 1 : 0)) {
+    case 2: hipLaunchKernelGGL((photometric_train_kernel<1, false>), grid, block, 0, st, a); break;
+    case 3: hipLaunchKernelGGL((photometric_train_kernel<1, true>), grid, block, 0, st, a); break;
+    case 4: hipLaunchKernelGGL((photometric_train_kernel<2, false>), grid, block, 0, st, a); break;
+    case 5: hipLaunchKernelGGL((photometric_train_kernel<2, true>), grid, block, 0, st, a); break;
+    case 6: hipLaunchKernelGGL((photometric_train_kernel<3, false>), grid, block, 0, st, a); break;
+    case 7: hipLaunchKernelGGL((photometric_train_kernel<3, true>), grid, block, 0, st, a); break;
+    case 8: hipLaunchKernelGGL((photometric_train_kernel<4, false>), grid, block, 0, st, a); break;
+    case 9: hipLaunchKernelGGL((photometric_train_kernel<4, true>), grid, block, 0, st, a); break;
     default: return MDX_ERR_BAD_SHAPE;
     }
     if (t && t->stop) (void)hipEventRecord((hipEvent_t)t->stop, st);
     if ((rc = check_launch())) return rc;
     FinishArgs fa = {};
-    fa.B = d->B; fa.H = d->H; fa.W = d->W; fa.nscales = d->nscales; fa.S = d->S; fa.ipi = p.nchunks * p.nstrips;
+    fa.B = d->B; fa.H = d->H; fa.W = d->W; fa.nscales = d->nscales; fa.S = grad ? d->S : 0; fa.ipi = p.nchunks * p.nstrips;
     fa.partP = a.partP; fa.loss_part = a.loss_part; fa.gP = gP; fa.loss_sum = loss_sum;
     int nblk = 0;
     bool separate[MDX_MAX_SCALES] = {false, false, false, false};
     for (int s = 0; s < MDX_MAX_SCALES; ++s) {
         fa.up_first[s] = nblk;
         const int ss = s < d->nscales ? s : 0;
-        fa.gup[s] = a.gup[ss]; fa.gin[s] = gdisp[ss]; fa.h[s] = d->h[ss]; fa.w[s] = d->w[ss];
+        fa.gup[s] = a.gup[ss]; fa.gin[s] = grad ? gdisp[ss] : nullptr; fa.h[s] = d->h[ss]; fa.w[s] = d->w[ss];
         fa.ratio[s] = 2; fa.tiles_x[s] = fa.tiles_y[s] = 1;
-        if (s >= d->nscales || (d->h[s] == d->H && d->w[s] == d->W)) continue;
+        if (!grad || s >= d->nscales || (d->h[s] == d->H && d->w[s] == d->W)) continue;
 #ifdef MDX_TRAIN_STAMPS
         if (const char *e = getenv("MDX_FINISH_SKIP")) if (strchr(e, '0' + s)) continue;   // diagnostic: leave a scale out
 #endif
@@ -1048,7 +1100,7 @@ MDX_EXPORT int mdx_photometric_train(const mdx_train_desc *d, const float *const
         nblk += fa.tiles_x[s] * fa.tiles_y[s] * d->B;
     }
     fa.up_first[MDX_MAX_SCALES] = nblk;
-    const int ngp_blocks = (d->nscales * d->S * d->B * 12 + NT / 64 - 1) / (NT / 64);
+    const int ngp_blocks = (d->nscales * fa.S * d->B * 12 + NT / 64 - 1) / (NT / 64);
     hipLaunchKernelGGL(train_finish_kernel, dim3(nblk + ngp_blocks + d->nscales), dim3(NT), 0, st, fa);
     if ((rc = check_launch())) return rc;
     for (int s = 0; s < d->nscales; ++s)

@@ -212,21 +212,24 @@ class _PhotometricTrain(torch.autograd.Function):
             noises = [_f32c(x) for x in noises]
         idx = [torch.empty(B, H, W, device=dev, dtype=torch.uint8) for _ in range(nsc)]
         sums = torch.empty(nsc, device=dev, dtype=torch.float32)
-        gdisp = [torch.empty_like(x) for x in disps]
-        gP = torch.empty(nsc, S, B, 3, 4, device=dev, dtype=torch.float32)
+        grads = cfg.get("grads", True)         # False: every scale's forward alone (validation / torch.no_grad())
+        gdisp = [torch.empty_like(x) for x in disps] if grads else None
+        gP = torch.empty(nsc, S, B, 3, 4, device=dev, dtype=torch.float32) if grads else None
         depth0 = torch.empty(B, 1, H, W, device=dev, dtype=torch.float32) if cfg.get("need_depth") else None
         to_opt = [torch.empty(B, H, W, device=dev, dtype=torch.float32) for _ in range(nsc)] \
             if cfg.get("need_to_opt") else None
         nws = lib().mdx_photometric_train_workspace_bytes(C.byref(d))
         ws = torch.empty(nws // 16 + 1, 2, dtype=torch.float64, device=dev)
-        hook = _timing_hook("train")
+        hook = _timing_hook("train" if grads else "eval")
         check(lib().mdx_photometric_train(
             C.byref(d), _lib.ptr_array(disps), ptr(target), C.byref(src), ptr(invK), _lib.ptr_array(Ps),
             ptr(ident) if automask else None, _lib.ptr_array(noises) if automask else None,
-            _lib.ptr_array(idx, torch.uint8), ptr(sums), _lib.ptr_array(gdisp), ptr(gP), ptr(depth0, optional=True),
+            _lib.ptr_array(idx, torch.uint8), ptr(sums), _lib.ptr_array(gdisp) if grads else None,
+            ptr(gP) if grads else None, ptr(depth0, optional=True),
             _lib.ptr_array(to_opt) if to_opt is not None else None, ptr(ws, torch.float64), C.c_size_t(nws), stream(),
             C.byref(hook) if hook is not None else None), "mdx_photometric_train")
-        ctx.save_for_backward(gP, *gdisp)
+        if grads:
+            ctx.save_for_backward(gP, *gdisp)
         ctx.per_scale_P = per_scale_P
         extras = idx + [depth0] + (to_opt if to_opt is not None else [])
         ctx.mark_non_differentiable(*[t for t in extras if t is not None])
@@ -243,7 +246,9 @@ class _PhotometricTrain(torch.autograd.Function):
 
 def photometric_train(disps, P, target, sources, invK, ident=None, noises=None, automask=True, min_depth=0.1,
                       max_depth=100.0, need_depth=False, need_to_opt=False, rows_per_chunk=0):
-    """The training step's photometric term for every scale at once: forward and gradient in one launch.
+    """The training step's photometric term for every scale at once: forward and gradient in one launch.  Under
+    torch.no_grad() (or when nothing requires a gradient) the forward-only form of the same kernel runs: every scale's
+    loss sum, indices and depth in one launch, nothing computed or kept for a backward.
 
     disps: list of [B,1,h_s,w_s] (grad); P [S,B,3,4] (grad) shared by the scales, or a list with one P per scale
     (posecnn: the translation is scaled by the scale's mean inverse depth, processor.py:153-157);
@@ -252,8 +257,10 @@ def photometric_train(disps, P, target, sources, invK, ident=None, noises=None, 
     Pl = list(P) if isinstance(P, (list, tuple)) else [P]
     if len(Pl) not in (1, len(disps)):
         raise _lib.MdxError("photometric_train: %d projections for %d scales (one, or one per scale)" % (len(Pl), len(disps)))
+    grads = torch.is_grad_enabled() and any(t.requires_grad for t in list(disps) + Pl)
     cfg = dict(automask=bool(automask), min_depth=float(min_depth), max_depth=float(max_depth),
-               need_depth=bool(need_depth), need_to_opt=bool(need_to_opt), rows_per_chunk=int(rows_per_chunk))
+               need_depth=bool(need_depth), need_to_opt=bool(need_to_opt), rows_per_chunk=int(rows_per_chunk),
+               grads=grads)
     n = len(disps)
     out = _PhotometricTrain.apply(target, invK, ident, cfg, list(noises) if noises is not None else None,
                                   list(sources), len(Pl), *Pl, *disps)

@@ -199,7 +199,10 @@ class image_prep(object):
         drop = ("raw_size", "raw_flip", "raw_jitter", "depth_hw", ("depth_idx", 0), ("depth_val", 0))
         out = {k: v for k, v in batch.items() if not (isinstance(k, tuple) and k[0] == "raw") and k not in drop}
         if ("depth_idx", 0) in batch:     # sparse velodyne ground truth -> the dense [B,1,h,w] map the loader's contract names
-            gh, gw = (int(v) for v in batch["depth_hw"][0].tolist())
+            hw = batch["depth_hw"].tolist()
+            if any(row != hw[0] for row in hw):     # the sparse indices of every sample address ONE [gh, gw] grid
+                raise _lib.MdxError("image_prep: the ground-truth maps of a batch must share one size, got %s" % (sorted(set(map(tuple, hw))),))
+            gh, gw = (int(v) for v in hw[0])
             idx = batch[("depth_idx", 0)].to(self.device, non_blocking=True).long()
             val = batch[("depth_val", 0)].to(self.device, non_blocking=True)
             buf = torch.zeros(idx.shape[0], gh * gw + 1, device=self.device)       # + one slot that takes the padding

@@ -55,6 +55,10 @@ def options(argv=None):
                    help="restart after this many finished epochs from ./model_save/<save>/ (weights <key><N>.pt + state<N>.pt)")
     p.add_argument("--synthetic_pool", type=int, default=0, help="synthetic dataset: number of distinct samples kept (0 = all)")
     p.add_argument("--noise", type=str, default="device", choices=["device", "cpu"])
+    p.add_argument("--grad_comm", type=str, default="fp32", choices=["fp32", "bf16"],
+                   help="data parallel: dtype of the gradient all-reduce (bf16 halves the bytes over xGMI; gradients rounded once)")
+    p.add_argument("--bucket_mb", type=int, default=0,
+                   help="data parallel: size of an all-reduce bucket (0 = one bucket for a captured step, 32 MB eager)")
     p.add_argument("--amp", type=str, default="none", choices=["none", "bf16"])
     p.add_argument("--channels_last", action="store_true")
     p.add_argument("--synthetic_length", type=int, default=768)

@@ -1,6 +1,6 @@
 """`setting`: builds loaders, networks, projection modules, losses and the optimiser
-(reference: model_tool/loader.py:16-119), plus what the reference never had: one process per GPU with
-DistributedDataParallel over RCCL (torch.distributed backend "nccl" on ROCm) and a rank-sharded sampler.
+(reference: model_tool/loader.py:16-119), plus what the reference never had: one process per GPU, a rank-sharded
+sampler and the gradient all-reduce over RCCL (torch.distributed backend "nccl" on ROCm; model_tool/parallel.py).
 """
 import os
 
@@ -45,12 +45,15 @@ class setting(object):
         self.num_pose_frames = len(opt.frame_ids) if opt.pose_frames == "all" else 2
         self.world_size = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
-        self.distributed = self.world_size > 1 and torch.distributed.is_available() and torch.distributed.is_initialized()
+        # a process group makes the run data-parallel -- also a group of ONE rank (the full exchange path on one GPU)
+        self.distributed = torch.distributed.is_available() and torch.distributed.is_initialized()
+        if self.distributed:
+            self.world_size, self.rank = torch.distributed.get_world_size(), torch.distributed.get_rank()
 
         self.train_dataloader = self.set_loader("train", True, True)
         self.valid_dataloader = self.set_loader("val", False, False)
         self.model = {}
-        self.ddp = {}
+        self.sync = None
         self.parameters = []
         self.set_model()
         self.loss = {}
@@ -114,20 +117,20 @@ class setting(object):
                     p.requires_grad_(False)
             self.model[key] = m
             self.parameters += [p for p in m.parameters() if p.requires_grad]
+        self.raw_model = self.model
         if self.distributed:
-            from torch.nn.parallel import DistributedDataParallel as DDP
-            dev_ids = [torch.device(self.device).index] if str(self.device).startswith("cuda") else None
-            for key in list(self.model):
-                self.ddp[key] = DDP(self.model[key], device_ids=dev_ids, bucket_cap_mb=_opt(opt, "bucket_mb", 32),
-                                    gradient_as_bucket_view=True, broadcast_buffers=False)
-            self.raw_model = dict(self.model)
-            self.model = dict(self.ddp)
-            # attributes the step driver reads from the bare modules
-            for key in self.model:
-                if hasattr(self.raw_model[key], "num_ch_enc"):
-                    self.model[key].num_ch_enc = self.raw_model[key].num_ch_enc
-        else:
-            self.raw_model = self.model
+            # one flat gradient buffer + bucketed all-reduce(mean) issued from inside backward (model_tool/parallel.py):
+            # capturable together with the rest of the step; buffers (batch-norm statistics) stay per GPU as in the
+            # single-device reference, parameters start from rank 0's
+            from .parallel import grad_sync, broadcast_state
+            broadcast_state(self.model.values())
+            comm = {"fp32": None, "bf16": torch.bfloat16}[str(_opt(opt, "grad_comm", "fp32"))]
+            # a captured step exchanges ONE bucket when backward ends; an eager one overlaps 32 MB buckets with backward
+            # (measured: model_tool/parallel.py)
+            captured = bool(_opt(opt, "graph", False)) and str(self.device).startswith("cuda") \
+                and str(_opt(opt, "noise", "device")) != "cpu" and torch.distributed.get_backend() == "nccl"
+            mb = int(_opt(opt, "bucket_mb", 0)) or ((1 << 20) if captured else 32)
+            self.sync = grad_sync(self.parameters, bucket_mb=mb, comm_dtype=comm)
 
     # reference: loader.py:99-103
     def set_loss(self):

@@ -52,12 +52,22 @@ class control(object):
             return float(torch.stack([v.float().reshape(()) for v in values]).mean().cpu())
         return float(np.mean(values))
 
+    def epoch_means(self, log):
+        """{metric: mean over the epoch} -- over every rank's batches when the run is data-parallel (the reference's
+        logger prints the mean of everything the run saw, logger.py:30-48): ONE all-reduce of the 8 scalars, which every
+        rank must enter."""
+        from .parallel import mean_over_ranks
+        local = [self._mean(log[key]) for key in self.metric_name]
+        return dict(zip(self.metric_name, mean_over_ranks(local, self.device)))
+
     def print(self, epoch, train_log, valid_log):
+        """logs: {metric: per-batch values} (reference signature, logger.py:37-48) or {metric: epoch mean}."""
         print("EPOCH   {0}".format(epoch + 1))
         for name, log in (("Train Log", train_log), ("Valid Log", valid_log)):
             print(name, end=" ")
             for key in self.metric_name:
-                print("  {} {:0.3f}".format(key, self._mean(log[key])), end=" ")
+                v = log[key]
+                print("  {} {:0.3f}".format(key, self._mean(v) if isinstance(v, (list, tuple)) else float(v)), end=" ")
             print(" ")
 
     def save(self, epoch, train_log, valid_log, setting):
@@ -72,24 +82,33 @@ class control(object):
                 torch.save(models[key].state_dict(), os.path.join(save_directory, key + str(epoch + 1) + ".pt"))
             # what a restart needs beyond the reference's files (it saves weights only, logger.py:51-68)
             torch.save({"epoch": epoch + 1, "optimizer": setting.optim["optimizer"].state_dict(),
-                        "scheduler": setting.optim["scheduler"].state_dict()},
+                        "scheduler": setting.optim["scheduler"].state_dict(),
+                        "train_log": {k: list(v) for k, v in train_log.items()},
+                        "valid_log": {k: list(v) for k, v in valid_log.items()}},
                        os.path.join(save_directory, "state" + str(epoch + 1) + ".pt"))
         if (epoch + 1) == self.opt.epoch:
             for key in self.metric_name:
                 np.save(os.path.join(loss_directory, key + ".npy"), np.asarray(valid_log[key]))
                 np.save(os.path.join(loss_directory, "train_" + key + ".npy"), np.asarray(train_log[key]))
 
-    def resume(self, setting, epoch):
+    def resume(self, setting, epoch, train_log=None, valid_log=None):
         """Restart from the files `save` wrote after `epoch` epochs (every rank loads them): network weights from the
-        reference-named `<key><epoch>.pt`, optimiser and scheduler from `state<epoch>.pt`.  -> the epoch to go on with."""
+        reference-named `<key><epoch>.pt`, optimiser, scheduler and the per-epoch logs so far (so that the loss/*.npy
+        files of the finished run cover every epoch) from `state<epoch>.pt`.  `epoch` must be one `save` wrote a
+        checkpoint for: the even ones and the last (the reference's schedule, logger.py:60).  -> the epoch to go on with."""
         save_directory = os.path.join("./model_save", self.opt.save)
         models = getattr(setting, "raw_model", setting.model)
         for key in models:
             path = os.path.join(save_directory, key + str(epoch) + ".pt")
             if not os.path.exists(path):
-                raise FileNotFoundError("cannot resume from epoch %d: %s is missing" % (epoch, path))
+                raise FileNotFoundError("cannot resume from epoch %d: %s is missing (checkpoints are written after even "
+                                        "epochs and after the last one)" % (epoch, path))
             models[key].load_state_dict(torch.load(path, map_location=self.device))
         state = torch.load(os.path.join(save_directory, "state" + str(epoch) + ".pt"), map_location=self.device)
         setting.optim["optimizer"].load_state_dict(state["optimizer"])
         setting.optim["scheduler"].load_state_dict(state["scheduler"])
+        for mine, key in ((train_log, "train_log"), (valid_log, "valid_log")):
+            if mine is not None and key in state:
+                for k in mine:
+                    mine[k][:0] = list(state[key].get(k, []))
         return int(state["epoch"])

@@ -1,0 +1,167 @@
+"""`grad_sync`: the one exchange of a data-parallel step -- all-reduce(mean) of the gradients over the GPUs of a node
+(RCCL over xGMI: torch.distributed backend "nccl" on ROCm) -- built so that the WHOLE step, exchange included, can be
+captured into one hipGraph (model_train.graphed_step).  The reference is single-device (model_train.py:28,54-96).
+
+Why not torch's DistributedDataParallel (round 2 wrapped each of the four networks in one): its reducer keeps
+host-side state per backward (bucket bookkeeping, unused-parameter logic, four sets of autograd hooks here) -- the
+captured step had to be switched off whenever WORLD_SIZE > 1, and an eager step of this model is host-bound with the
+loader's workers alive (~1600 launches).  Here:
+
+  * ONE flat float32 buffer holds every trainable parameter's gradient, allocated once (static addresses), cut into
+    buckets along the order in which backward produces gradients (reverse registration order: pose networks, depth
+    decoder, depth encoder);
+  * autograd writes its gradients where it likes (`.grad` is None before backward, so the accumulation node keeps the
+    tensor the last backward kernel produced: no extra pass).  A post-accumulate hook counts a bucket's parameters
+    down; when the last one is written the bucket's gradients are gathered into the flat buffer by ONE multi-tensor
+    copy, `.grad` of its parameters is re-pointed at the views (what Adam will read) and the bucket's all-reduce is
+    issued -- asynchronously, on the communicator's stream;
+  * `finish()` issues what no hook issued (a parameter that received no gradient contributes zeros), makes the current
+    stream wait for every exchange and, where the backend has no AVG reduction (gloo), divides by the world size.
+    No host synchronisation, no per-step Python state that a graph replay would skip.
+
+Measured on one MI355X with a process group of one rank (profiles/r03_dp_step.txt): gathering into the flat buffer
+costs what the in-place accumulation of round 3's first version did not (that version pre-set `.grad` to the views:
++0.39 ms = 250 read-modify-write kernels and a 107 MB memset per step).  EAGER, four 32 MB buckets overlap backward at
+no cost.  CAPTURED, every bucket that overlaps backward is a fork / join in the hipGraph and costs ~0.37 ms of graph
+execution (four buckets: +1.1 ms against one) -- more than the ~0.25 ms of xGMI time it could hide -- so a captured
+step uses ONE bucket, issued when backward ends (`setting` picks bucket_mb accordingly).
+
+xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce of the 107 MB (ResNet-18 depth + pose, fp32) is
+link-bound at ~0.5-1 ms against a >=13 ms step.  `comm_dtype=torch.bfloat16` halves the bytes (gradients are rounded
+once before the sum; off by default)."""
+import os
+
+import torch
+import torch.distributed as dist
+
+# measurement switches (tools/r3_step2.sh): leave the collective out / issue it synchronously
+_NO_COMM = os.environ.get("MDX_SYNC_NO_COMM") == "1"
+_SYNC_COMM = os.environ.get("MDX_SYNC_BLOCKING") == "1"
+
+
+def _align(n, a=64):
+    return (n + a - 1) // a * a
+
+
+class grad_sync(object):
+    def __init__(self, parameters, bucket_mb=32, group=None, comm_dtype=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.backend = dist.get_backend(group)
+        self.params = [p for p in parameters if p.requires_grad]
+        if not self.params:
+            raise ValueError("grad_sync: no trainable parameters")
+        dev = self.params[0].device
+        if any(p.device != dev or p.dtype != torch.float32 for p in self.params):
+            raise ValueError("grad_sync: parameters must be float32 on one device")
+        order = list(reversed(self.params))                      # ~ the order backward writes them
+        cap = max(1, int(bucket_mb * (1 << 20) // 4))
+        self.offsets, self.buckets, self._bucket_of = {}, [], {}
+        off = start = 0
+        members = []
+        for p in order:
+            self.offsets[id(p)] = off
+            members.append(p)
+            off += _align(p.numel())                             # 256-byte aligned views
+            if off - start >= cap:
+                self.buckets.append((start, off, members))
+                start, members = off, []
+        if members:
+            self.buckets.append((start, off, members))
+        self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.comm = torch.zeros(off, dtype=comm_dtype, device=dev) if comm_dtype not in (None, torch.float32) else None
+        self._views = {}
+        for k, (_, _, members) in enumerate(self.buckets):
+            for p in members:
+                self._bucket_of[id(p)] = k
+                o = self.offsets[id(p)]
+                self._views[id(p)] = self.flat[o:o + p.numel()].view_as(p)
+        self._avg = self.backend == "nccl"                      # ncclAvg exists in RCCL; gloo only sums
+        self._works = []
+        self._reset()
+        self.zero()
+        self._hooks = [p.register_post_accumulate_grad_hook(self._ready) for p in self.params]
+
+    def zero(self):
+        """Instead of optimizer.zero_grad(): `.grad` = None, so backward's accumulation keeps the incoming tensor as
+        it is (no read-modify-write pass); the gather into the flat buffer overwrites, nothing needs clearing."""
+        for p in self.params:
+            p.grad = None
+
+    # -- exchange ---------------------------------------------------------------------------------
+    def _reset(self):
+        self._pending = [len(m) for _, _, m in self.buckets]
+        self._next = 0                     # buckets are issued strictly in order: every rank issues the same sequence
+
+    def _ready(self, p):
+        k = self._bucket_of[id(p)]
+        self._pending[k] -= 1
+        while self._next < len(self.buckets) and self._pending[self._next] <= 0:
+            self._issue(self._next)
+            self._next += 1
+
+    def _issue(self, k):
+        a, b, members = self.buckets[k]
+        dst, src = [], []
+        for p in members:
+            v = self._views[id(p)]
+            if p.grad is None:
+                v.zero_()                  # no gradient this step (never on this model's default path)
+            elif p.grad.data_ptr() != v.data_ptr():
+                dst.append(v)
+                src.append(p.grad)
+        if dst:
+            torch._foreach_copy_(dst, src)                       # one multi-tensor kernel
+        for p in members:
+            p.grad = self._views[id(p)]                          # what the optimiser reads: the reduced values
+        buf = self.flat[a:b]
+        if self.comm is not None:
+            cbuf = self.comm[a:b]
+            cbuf.copy_(buf)
+            buf = cbuf
+        if _NO_COMM:
+            return
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        self._works.append((k, dist.all_reduce(buf, op=op, group=self.group, async_op=not _SYNC_COMM)))
+
+    def finish(self):
+        """After backward: every bucket exchanged and visible to the current stream (no host synchronisation on GPU)."""
+        while self._next < len(self.buckets):
+            self._issue(self._next)
+            self._next += 1
+        for k, w in self._works:
+            if w is not None:
+                w.wait()                   # nccl: the current stream waits for the communicator's stream; gloo: blocks
+            if self.comm is not None:
+                a, b, _ = self.buckets[k]
+                self.flat[a:b].copy_(self.comm[a:b])
+        if not self._avg:
+            self.flat.mul_(1.0 / self.world)
+        self._works = []
+        self._reset()
+
+    def detach(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+
+def broadcast_state(modules, src=0, group=None):
+    """Every rank starts from rank `src`'s parameters and buffers (what DDP's constructor does)."""
+    with torch.no_grad():
+        for m in modules:
+            for t in list(m.parameters()) + list(m.buffers()):
+                dist.broadcast(t, src, group=group)
+
+
+def mean_over_ranks(values, device, group=None):
+    """Scalars (one per metric) averaged over the job: one all-reduce of len(values) numbers."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return [float(v) for v in values]
+    dev = device if dist.get_backend(group) == "nccl" else "cpu"
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=dev)
+    valid = torch.isfinite(t).to(torch.float64)
+    t = torch.where(valid > 0, t, torch.zeros_like(t))
+    both = torch.stack([t, valid])
+    dist.all_reduce(both, group=group)
+    return [float(s / c) if c > 0 else float("nan") for s, c in zip(both[0].tolist(), both[1].tolist())]

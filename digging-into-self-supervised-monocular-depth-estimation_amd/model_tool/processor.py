@@ -76,7 +76,12 @@ class compute(object):
             return inputs
         if self._prep is None:
             self._prep = image_prep(self.opt.height, self.opt.width, self.opt.frame_ids, len(self.opt.scales), self.device)
-        return self._prep(inputs)
+        # IN PLACE, as the reference's forward_depth treats its dictionary (processor.py:34-35): the caller's batch is the
+        # one control.metric reads ("depth", 0) from afterwards
+        prepared = self._prep(inputs)
+        inputs.clear()
+        inputs.update(prepared)
+        return inputs
 
     def forward_depth(self, inputs, outputs, setting):
         dev = torch.device(self.device)
@@ -227,8 +232,8 @@ class compute(object):
             ident = F.identity_loss(target, sources)          # once per step (scale-independent)
         # training: every scale's photometric term and its gradient in one launch (posecnn: one projection per scale)
         train = None
-        if (self.fused and self.fused_train and torch.is_grad_enabled()
-                and len(opt.scales) <= 4 and any(outputs[("disp", s)].requires_grad for s in opt.scales)):
+        # (validation, torch.no_grad(): the same launch in its forward-only form)
+        if self.fused and self.fused_train and len(opt.scales) <= 4:
             nsc = len(opt.scales)
             noises = None
             if automask:

@@ -47,14 +47,19 @@ class device_prefetcher(object):
 
 
 class graphed_step(object):
-    """One training step (networks, the photometric kernels launched through the C-ABI, fused Adam) captured into ONE
-    hipGraph and replayed: ~1600 kernel launches leave the host's critical path, so the step stays GPU-bound while the
-    host decodes and collates the next batches (measured: with 12 loader workers alive the eager step needs 24.5 ms of
-    host time for 20.7 ms of GPU time).  Inputs live in static device buffers the batch is copied into; the outputs the
-    loop reads afterwards (loss, depth of scale 0, auto-masks) are the graph's own tensors.  What Python does during a
-    step and a replay would skip is re-applied per replay: the batch-norm step counters.  Single-process training only
-    (under DDP the eager step runs); any change of the learning rate goes through set_lr (a device tensor the captured
-    Adam reads)."""
+    """One training step (networks, the photometric kernels launched through the C-ABI, the gradient all-reduce of a
+    data-parallel job, fused Adam) captured into ONE hipGraph and replayed: ~1600 kernel launches leave the host's
+    critical path, so the step stays GPU-bound while the host decodes and collates the next batches (measured: with 12
+    loader workers alive the eager step needs 24.5 ms of host time for 20.7 ms of GPU time).  Inputs live in static
+    device buffers the batch is copied into; the outputs the loop reads afterwards (loss, depth of scale 0, auto-masks)
+    are the graph's own tensors.  What Python does during a step and a replay would skip is re-applied per replay: the
+    batch-norm step counters.  Under torch.distributed the exchange (model_tool/parallel.py: bucketed RCCL all-reduce
+    issued from inside backward) is part of the graph.  Any change of the learning rate goes through set_lr (a device
+    tensor the captured Adam reads).
+
+    The warm-up steps capture needs (MIOpen picks its kernels, the allocator settles, RCCL opens its communicator) are
+    side-effect free: weights, batch-norm statistics, Adam moments and step counters are put back afterwards, so the
+    first replay is step 1 of the run -- graph on and graph off follow the same trajectory."""
 
     def __init__(self, tr, example, warmup=3):
         self.tr = tr
@@ -69,21 +74,47 @@ class graphed_step(object):
         self.static = {k: (v.to(dev).clone() if torch.is_tensor(v) and wanted(k) else v) for k, v in example.items()}
         self.copied = {k for k, v in example.items() if torch.is_tensor(v) and wanted(k)}
         from model_layer.depth_encoder import BatchNorm2d
-        self.bns = [m for net in tr.setting.raw_model.values() for m in net.modules() if isinstance(m, BatchNorm2d)]
-        side = torch.cuda.Stream(dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
+        nets = list(tr.setting.raw_model.values())
+        self.bns = [m for net in nets for m in net.modules() if isinstance(m, BatchNorm2d)]
+        # ---- snapshot of everything a training step changes ----
+        tensors = [t for net in nets for t in list(net.parameters()) + list(net.buffers())]
+        saved = [t.detach().clone() for t in tensors]
+        saved_bn = [m._pending_batches for m in self.bns]
+        had_state = {id(p): {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in st.items()}
+                     for p, st in opt.state.items()}
+        # ONE side stream for the warm-up and the capture: the gradient-accumulation nodes autograd creates during
+        # the captured forward then live on the stream that produces their gradients
+        self.stream = torch.cuda.Stream(dev)
+        self.stream.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(self.stream):
             for _ in range(warmup):
                 tr._eager_step(dict(self.static))
-        torch.cuda.current_stream(dev).wait_stream(side)
+            with torch.no_grad():
+                for t, v in zip(tensors, saved):
+                    t.copy_(v)
+                for p, st in opt.state.items():
+                    old = had_state.get(id(p))
+                    for k, v in st.items():
+                        if torch.is_tensor(v):
+                            if old is not None and k in old:
+                                v.copy_(old[k])
+                            else:
+                                v.zero_()          # Adam's initial state: zero moments, step 0
+            for m, n in zip(self.bns, saved_bn):
+                m._pending_batches = n
+        torch.cuda.current_stream(dev).wait_stream(self.stream)
         torch.cuda.synchronize(dev)
+        del saved, had_state
         before = [m._pending_batches for m in self.bns]
         self.graph = torch.cuda.CUDAGraph()
         # thread_local: the DataLoader's pin-memory thread keeps allocating pinned host buffers for the next batches
-        # while this thread captures; in the default "global" mode such a call from ANY thread invalidates the capture
-        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+        # (and RCCL's watchdog thread polls events) while this thread captures; in the default "global" mode such a
+        # call from ANY thread invalidates the capture
+        with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="thread_local"):
             self.outputs = tr._eager_step(dict(self.static))
         self.bn_incr = [m._pending_batches - b for m, b in zip(self.bns, before)]
+        for m, b in zip(self.bns, before):         # the capture pass ran no kernel: it was not a step
+            m._pending_batches = b
         torch.cuda.synchronize(dev)
 
     def set_lr(self, value):
@@ -111,7 +142,11 @@ class trainer(object):
         else:
             self.device = "cpu"
         if world > 1 and not torch.distributed.is_initialized():
-            torch.distributed.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+            if torch.cuda.is_available():
+                torch.distributed.init_process_group(os.environ.get("MDX_DIST_BACKEND", "nccl"),
+                                                     device_id=torch.device(self.device))
+            else:
+                torch.distributed.init_process_group("gloo")
         self.rank = int(os.environ.get("RANK", "0"))
         from mdx.tuning import install_miopen_db
         install_miopen_db(self.rank)          # tuned conv / batch-norm solvers for the default shapes (immediate mode)
@@ -135,17 +170,30 @@ class trainer(object):
         return outputs
 
     def _eager_step(self, inputs):
+        """forward, backward, (data parallel: gradient all-reduce, overlapped with backward), Adam."""
         outputs = self.batch_process(inputs)
-        self.setting.optim["optimizer"].zero_grad(set_to_none=True)
+        sync = self.setting.sync
+        if sync is None:
+            self.setting.optim["optimizer"].zero_grad(set_to_none=True)
+        else:
+            sync.zero()                    # the gradients are views into one flat buffer: one memset
         outputs["loss"].backward()
+        if sync is not None:
+            sync.finish()
         self.setting.optim["optimizer"].step()
         return outputs
 
+    def can_graph(self):
+        """The step is capturable when nothing in it runs on the host: not with the reference's host-side noise
+        (--noise cpu: torch.randn on the CPU + a copy from pageable memory), not with a non-RCCL process group."""
+        sync = self.setting.sync
+        return (str(self.device).startswith("cuda") and self.compute.noise_mode != "cpu"
+                and (sync is None or sync.backend == "nccl"))
+
     def train_step(self, inputs):
-        """opt.graph (single process, GPU): the step is captured once into a hipGraph and replayed (graphed_step);
-        otherwise eager."""
-        use_graph = (getattr(self.opt, "graph", False) and str(self.device).startswith("cuda")
-                     and not self.setting.distributed)
+        """opt.graph (GPU): the step -- under torch.distributed including the gradient exchange -- is captured once
+        into a hipGraph and replayed (graphed_step); otherwise eager."""
+        use_graph = getattr(self.opt, "graph", False) and self.can_graph()
         if not use_graph:
             return self._eager_step(inputs)
         inputs = self.compute.prepare(inputs)     # decoded frames -> step entries (a no-op after the prefetcher)
@@ -160,7 +208,9 @@ class trainer(object):
         names = self.control.metric_name
         epoch_train = {k: [] for k in names}
         epoch_valid = {k: [] for k in names}
-        start = self.control.resume(self.setting, self.opt.resume) if getattr(self.opt, "resume", 0) else 0
+        start = 0
+        if getattr(self.opt, "resume", 0):     # weights, optimiser, scheduler and the per-epoch logs so far
+            start = self.control.resume(self.setting, self.opt.resume, epoch_train, epoch_valid)
         for epoch in range(start, self.opt.epoch):
             batch_train = {k: [] for k in names}
             batch_valid = {k: [] for k in names}
@@ -186,11 +236,13 @@ class trainer(object):
                 self._graphed.set_lr(lr)
                 for g in self.setting.optim["optimizer"].param_groups:
                     g["lr"] = self._graphed.lr
+            # epoch means over everything the JOB saw: one all-reduce of the 2 x 8 scalars (every rank takes part)
+            mean_train, mean_valid = self.control.epoch_means(batch_train), self.control.epoch_means(batch_valid)
             for key in names:
-                epoch_train[key].append(self.control._mean(batch_train[key]))
-                epoch_valid[key].append(self.control._mean(batch_valid[key]))
+                epoch_train[key].append(mean_train[key])
+                epoch_valid[key].append(mean_valid[key])
             if self.rank == 0:
-                self.control.print(epoch, batch_train, batch_valid)
+                self.control.print(epoch, mean_train, mean_valid)
             self.control.save(epoch, epoch_train, epoch_valid, self.setting)
 
 

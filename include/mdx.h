@@ -166,6 +166,8 @@ size_t mdx_photometric_train_workspace_bytes(const mdx_train_desc *d);
  * Outputs: idx[s] [B,H,W] uint8; loss_sum [nscales]; gdisp[s] [B,1,h[s],w[s]]; gP [nscales,S,B,3,4];
  *   optional depth0 [B,1,H,W] (depth of scale 0, outputs[("depth",0,0)]); optional to_opt (array may be NULL,
  *   entries may be NULL) [B,H,W].
+ * gdisp == NULL and gP == NULL (both): every scale's FORWARD alone -- loss sums, indices, depth0, to_opt -- in one
+ *   launch: what the validation loop (model_train.py:75-79, under torch.no_grad()) and model_test.py need.
  * t (optional): events recorded right before / after the fused kernel. */
 int mdx_photometric_train(const mdx_train_desc *d, const float *const *disp, const float *target,
                           const mdx_sources *src, const float *invK, const float *const *P, const float *ident,

@@ -39,7 +39,11 @@ def f16_exact(t):
     return t.half().float()
 
 
-def run_full_case(name="r2_full_192x640_b1", B=1, H=192, W=640, seed=21, scales=(0, 2)):
+def run_full_case(name="r2_full_192x640_b1", B=1, H=192, W=640, seed=21, scales=(0, 2), shifts=None, tx=None,
+                  disp_noise=0.3, disp_lo=1.0, margin=16):
+    """shifts / tx (round 3, tests/golden/make_golden_r3.py): source frame f is the target moved by shifts[f] pixels and
+    its pose translates by tx[f] along x, so that the warp re-aligns most of it -- the reprojection channels then win
+    on most pixels (few auto-masked).  Defaults reproduce the round-2 fixture byte for byte."""
     frame_ids = [0, -1, 1]
     gen = torch.Generator().manual_seed(seed)
     torch.manual_seed(seed + 1000)
@@ -54,9 +58,9 @@ def run_full_case(name="r2_full_192x640_b1", B=1, H=192, W=640, seed=21, scales=
     store, inputs, outputs = {}, {}, {}
     # image-like colours: the target, and sources that are shifted copies of it plus a little texture (so that the
     # reprojection channels win on most pixels and the auto-mask takes the rest), uint8
-    base = G1.synth_image_u8(gen, B, H, W + 16).float()
+    base = G1.synth_image_u8(gen, B, H, W + margin).float()
     for k, f in enumerate(frame_ids):
-        sh = {0: 8, -1: 5, 1: 11}[f]
+        sh = (shifts or {0: 8, -1: 5, 1: 11})[f]
         img = base[..., sh:sh + W] + (4.0 * torch.randn(B, 3, H, W, generator=gen) if f else 0)
         u8 = img.clamp(0, 255).round().to(torch.uint8)
         store["color_u8_%s" % f] = u8.numpy()
@@ -72,8 +76,8 @@ def run_full_case(name="r2_full_192x640_b1", B=1, H=192, W=640, seed=21, scales=
     disps = {}
     for s in scales:
         lo = torch.randn(B, 1, max(H >> (s + 3), 2), max(W >> (s + 3), 2), generator=gen)
-        d = torch.sigmoid(torch.nn.functional.interpolate(lo, size=(H >> s, W >> s), mode="bilinear", align_corners=False)
-                          + 0.3 * torch.randn(B, 1, H >> s, W >> s, generator=gen))
+        d = torch.sigmoid(disp_lo * torch.nn.functional.interpolate(lo, size=(H >> s, W >> s), mode="bilinear", align_corners=False)
+                          + disp_noise * torch.randn(B, 1, H >> s, W >> s, generator=gen))
         d = f16_exact(d).requires_grad_(True)
         disps[s] = d
         outputs[("disp", s)] = d
@@ -82,6 +86,9 @@ def run_full_case(name="r2_full_192x640_b1", B=1, H=192, W=640, seed=21, scales=
     for f in frame_ids[1:]:
         aa = 0.01 * torch.randn(B, 1, 3, generator=gen)
         tr = 0.03 * torch.randn(B, 1, 3, generator=gen)
+        if tx is not None:
+            aa, tr = 0.1 * aa, 0.1 * tr
+            tr[..., 0] += tx[f]
         T = WARP.param2matrix(aa, tr, invert=(f < 0)).detach().clone().requires_grad_(True)
         Ts[f] = T
         outputs[("c2c", f, 0)] = T
@@ -189,7 +196,11 @@ def run_metrics(name="r2_metrics"):
     ys, xs = torch.randint(0, 375, (B, n), generator=gen), torch.randint(0, 1242, (B, n), generator=gen)
     vals = f16_exact(torch.rand(B, n, generator=gen) * 70 + 1.5)
     for b in range(B):
-        gtd[b, 0, ys[b], xs[b]] = vals[b]
+        # one value per pixel: a scatter with repeated indices keeps an unspecified one of them (the fixture could not
+        # be re-derived bit for bit); the first draw of a pixel wins
+        _, first = np.unique((ys[b] * 1242 + xs[b]).numpy(), return_index=True)
+        first = torch.from_numpy(np.sort(first))
+        gtd[b, 0, ys[b][first], xs[b][first]] = vals[b][first]
     out = metric.compute_depth_metric({("depth", 0): gtd.clone()}, {("depth", 0, 0): pdepth.clone()}, "torch")
     st["metric_pred_f16"] = pdepth.half().numpy()
     st["metric_gt_idx"] = torch.nonzero(gtd.reshape(-1)).reshape(-1).numpy().astype(np.int32)

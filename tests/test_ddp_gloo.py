@@ -1,4 +1,5 @@
-"""CPU: the multi-GPU path (one process per device, DDP, rank-sharded sampler) rehearsed with gloo, world_size 2."""
+"""CPU: the multi-GPU path (one process per device, flat gradient buffer + bucketed all-reduce, rank-sharded sampler,
+epoch metrics over the job) rehearsed with gloo, world_size 2."""
 import os
 import subprocess
 import sys
@@ -14,8 +15,12 @@ def _free_port():
         return sk.getsockname()[1]
 
 
-def test_ddp_world_size_2_gloo():
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+import pytest
+
+
+@pytest.mark.parametrize("comm", ["fp32", "bf16"])
+def test_ddp_world_size_2_gloo(comm):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", MDX_TEST_GRAD_COMM=comm)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "ddp_worker.py")]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)

@@ -177,43 +177,95 @@ def test_kitti_tree_training_and_eigen_style_evaluation(G, tmp_path):
     assert 0 <= res["a1"] <= res["a2"] <= res["a3"] <= 1
 
 
-def test_trainer_graph_replay_matches_eager(G):
-    """model_train.trainer with opt.graph: the step captured into one hipGraph and replayed gives the eager loop's
-    losses (auto-masking off: its noise stream differs between a captured and an eager generator), advances the
-    batch-norm step counters, and follows a learning-rate change."""
+def _trainer_losses(graph, automask=False, noise="device", n=6, lr_change_at=4):
     import importlib
     bench = importlib.import_module("bench")
     from model_train import trainer
+    torch.manual_seed(0)
+    opt = bench.make_opt(2, height=64, width=96)
+    opt.use_automasking, opt.graph, opt.synthetic_length, opt.max_steps, opt.miopen_find = automask, graph, 16, 0, False
+    opt.noise = noise
+    tr = trainer(opt)
+    tr.setting.set_train()
+    batches = list(tr.setting.train_dataloader)[:n]
+    torch.manual_seed(1)
+    losses = []
+    for i, b in enumerate(batches):
+        if i == lr_change_at:
+            for g in tr.setting.optim["optimizer"].param_groups:       # what StepLR does at an epoch boundary
+                if torch.is_tensor(g["lr"]):
+                    g["lr"].fill_(1e-6)
+                else:
+                    g["lr"] = 1e-6
+        losses.append(float(tr.train_step(dict(b))["loss"].detach()))
+    enc = tr.setting.raw_model["encoder"]
+    return losses, int(enc.state_dict()["encoder.bn1.num_batches_tracked"]), tr
 
-    def run(graph):
-        torch.manual_seed(0)
-        opt = bench.make_opt(2, height=64, width=96)
-        opt.use_automasking, opt.graph, opt.synthetic_length, opt.max_steps, opt.miopen_find = False, graph, 16, 0, False
-        tr = trainer(opt)
-        tr.setting.set_train()
-        batches = list(tr.setting.train_dataloader)[:6]
-        losses = []
-        for i, b in enumerate(batches):
-            if i == 4:
-                for g in tr.setting.optim["optimizer"].param_groups:       # what StepLR does at an epoch boundary
-                    if torch.is_tensor(g["lr"]):
-                        g["lr"].fill_(1e-6)
-                    else:
-                        g["lr"] = 1e-6
-            losses.append(float(tr.train_step(dict(b))["loss"].detach()))
-        enc = tr.setting.raw_model["encoder"]
-        return losses, int(enc.state_dict()["encoder.bn1.num_batches_tracked"]), tr
 
-    eager, n_eager, _ = run(False)
-    graph, n_graph, tr = run(True)
+def _same_trajectory(a, b):
+    assert all(np.isfinite(a)) and all(np.isfinite(b)), (a, b)
+    np.testing.assert_allclose(a[:3], b[:3], rtol=2e-4, atol=1e-6)     # float32 rounding / atomics-order differences ...
+    np.testing.assert_allclose(a, b, rtol=1e-2, atol=1e-5)             # ... which Adam amplifies step by step
+
+
+def test_trainer_graph_replay_matches_eager(G):
+    """model_train.trainer with opt.graph: the step captured into one hipGraph and replayed follows the eager loop's
+    TRAJECTORY -- the warm-up steps capture needs are undone (weights, batch-norm statistics and counters, Adam moments
+    and step counts), so the first replay is step 1 -- and follows a learning-rate change (auto-masking off: its noise
+    stream differs between a captured and an eager generator)."""
+    eager, n_eager, _ = _trainer_losses(False)
+    graph, n_graph, tr = _trainer_losses(True)
     assert tr._graphed is not None
-    assert n_graph == n_eager + 3 + 1          # + the graph's warm-up steps and its capture pass
-    # the graphed run takes 4 extra optimiser steps before its first replay (warm-up + capture): compare trends, and the
-    # replay against an eager step from the same state
-    assert all(np.isfinite(graph)) and graph[-1] < graph[0]
+    assert n_graph == n_eager == 6             # neither the warm-up nor the capture pass counts as a step
+    _same_trajectory(graph, eager)
+    step = [float(v["step"]) for v in tr.setting.optim["optimizer"].state.values()]
+    assert step and all(v == 6.0 for v in step), sorted(set(step))
     o1 = float(tr._eager_step(dict(tr._graphed.static))["loss"].detach())
     o2 = float(tr._graphed(dict(tr._graphed.static))["loss"].detach())
     assert np.isfinite(o1) and np.isfinite(o2) and abs(o1 - o2) < 0.05 * abs(o1)
+
+
+def test_trainer_host_noise_is_never_captured(G):
+    """--noise cpu (the reference's torch.randn on the host + copy, processor.py:195) cannot be part of a hipGraph: the
+    host draw would run once, at capture time.  The trainer then runs eager whatever opt.graph says, and the run is
+    the eager run (same host RNG stream)."""
+    eager, _, _ = _trainer_losses(False, automask=True, noise="cpu", n=4)
+    asked, _, tr = _trainer_losses(True, automask=True, noise="cpu", n=4)
+    assert tr._graphed is None and not tr.can_graph()
+    _same_trajectory(asked, eager)
+
+
+@pytest.fixture
+def rccl_group_of_one():
+    import torch.distributed as dist
+    import bench
+    assert not dist.is_initialized()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % bench.free_port(), rank=0, world_size=1,
+                            device_id=torch.device(torch.cuda.current_device()))
+    yield dist
+    dist.destroy_process_group()
+
+
+def test_trainer_captured_step_with_rccl_exchange(G, rccl_group_of_one):
+    """The data-parallel step on ONE GPU: a process group of one rank over RCCL makes `setting` build the flat gradient
+    buffer and issue its bucketed all-reduce from inside backward (model_tool/parallel.py).  Eager and captured (the
+    exchange inside the hipGraph) follow the single-process trajectory."""
+    plain, _, _ = None, None, None
+    eager, n_eager, tr_e = _trainer_losses(False)
+    assert tr_e.setting.sync is not None and tr_e.setting.sync.backend == "nccl" and tr_e._graphed is None
+    sync = tr_e.setting.sync
+    assert len(sync.buckets) >= 2 and all(p.grad.data_ptr() == sync.flat.data_ptr() + 4 * sync.offsets[id(p)] for p in sync.params)
+    graph, n_graph, tr_g = _trainer_losses(True)
+    assert tr_g.setting.sync is not None and tr_g._graphed is not None and tr_g.can_graph()
+    assert len(tr_g.setting.sync.buckets) == 1        # a captured step exchanges one bucket (model_tool/parallel.py)
+    assert n_graph == n_eager == 6
+    _same_trajectory(graph, eager)
+    # the metrics of an epoch go through the job-wide mean (one all-reduce over RCCL)
+    log = {k: [] for k in tr_g.control.metric_name}
+    log["loss"] = [torch.tensor(1.0, device=G.DEV), torch.tensor(2.0, device=G.DEV)]
+    assert abs(tr_g.control.epoch_means(log)["loss"] - 1.5) < 1e-12
+    for tr in (tr_e, tr_g):
+        tr.setting.sync.detach()
 
 
 def test_trainer_on_kitti_tree_gpu_image_prep_equals_pillow_loader(G, tmp_path):

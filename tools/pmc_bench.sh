@@ -1,0 +1,27 @@
+#!/bin/bash
+# PMC + kernel-trace passes over bench.py ITSELF: the counters of the photometric kernels are taken on the launches
+# (and tensors) of the very step bench.py times -- VERDICT r2 weak #2: round 2's counters came from tools/kbench.py's data.
+#   gpurun --timeout 1100 -- 'bash tools/pmc_bench.sh [extra bench.py args]'
+#   python tools/pmc_to_json.py gpurun_out/pmc_bench profiles/r03_bench_kernel_pmc.json 12 192 640 2 4
+# rocprofv3 rules on this pool: program directly after `--`, counters in their own passes (only --kernel-trace beside
+# --pmc), cwd /tmp.  --kernel-include-regex keeps the serialising counter collection off the ~1600 other launches of a step.
+set -o pipefail
+ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
+OUT="$ROOT/gpurun_out/pmc_bench"
+rm -rf "$OUT"; mkdir -p "$OUT" && cd /tmp && export TMPDIR=/tmp
+BENCH="$ROOT/bench.py --no-cpu-baseline --no-trainer-loop --no-roofline"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 $BENCH --steps 30 --warmup 10 "$@" > "$OUT/trace.log" 2>&1
+echo "trace rc=$?"
+i=0
+for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" \
+           "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
+           "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_RD" \
+           "SQ_INST_CYCLES_VMEM_RD SQ_INSTS_VMEM_WR SQ_IFETCH SQ_WAIT_INST_LDS" \
+           "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"; do
+    i=$((i + 1))
+    timeout -k 10 200 rocprofv3 --kernel-trace --pmc $grp --kernel-include-regex "mdx::(photometric|train_finish|smooth)" \
+        --output-format csv -d "$OUT/pmc_$i" -- python3 $BENCH --steps 6 --warmup 4 "$@" > "$OUT/pmc_$i.log" 2>&1
+    echo "pmc pass $i ($grp): rc=$?"
+done
+MDX_PMC_TITLE="python bench.py $*: the timed step's own launches; B=12, 192x640, S=2, four scales" MDX_PMC_FILTER="mdx::photometric,mdx::train_finish,mdx::smooth" python3 "$ROOT/tools/pmc_summary.py" "$OUT/summary.txt" "$OUT"/pmc_* > /dev/null
+cat "$OUT/summary.txt"

@@ -19,7 +19,8 @@ def main():
             for r in csv.DictReader(open(f)):
                 if any(f in r["Kernel_Name"] for f in FILTER):
                     agg[r["Kernel_Name"].replace("void ", "")[:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    lines = ["# rocprofv3 --pmc, mean per launch (tools/kbench.py: B=12, 192x640, S=2, all four scales)"]
+    lines = ["# rocprofv3 --pmc, mean per launch (%s)" % os.environ.get(
+        "MDX_PMC_TITLE", "tools/kbench.py: B=12, 192x640, S=2, all four scales")]
     for k in sorted(agg):
         lines.append(k)
         for c in sorted(agg[k]):

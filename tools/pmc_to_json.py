@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""rocprofv3 --pmc passes of tools/kbench.py --what train  ->  profiles/<tag>_train_kernel_pmc.json
+"""rocprofv3 --pmc passes of tools/pmc_bench.sh (bench.py's own launches) or tools/pmc_train.sh (tools/kbench.py)
+->  profiles/<tag>_..._kernel_pmc.json
 
-    python tools/pmc_to_json.py gpurun_out/pmc_train profiles/r02_train_kernel_pmc.json B H W S NSCALES
+    python tools/pmc_to_json.py gpurun_out/pmc_bench profiles/r03_bench_kernel_pmc.json B H W S NSCALES
 
 Per kernel: mean counters per launch; HBM-side traffic as MI355X_MICROARCH.md prescribes (FETCH_SIZE and WRITE_SIZE
 from separate passes, KiB; FETCH_SIZE x2 for gfx950's 64-B tally of 128-B requests -- calibrated there for wide
@@ -37,7 +38,17 @@ def main():
             name = r["Kernel_Name"].replace("void ", "").split("(")[0]
             dur[name].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     out = {"lib_sha16": hashlib.sha256(open(so, "rb").read()).hexdigest()[:16], "shape": shape,
-           "source": "tools/pmc_train.sh (tools/kbench.py --what train), means per launch", "kernels": {}}
+           "source": ("tools/pmc_bench.sh: rocprofv3 --pmc over `python bench.py` itself (the timed step's own launches and "
+                      "tensors), means per launch" if "pmc_bench" in src else
+                      "tools/pmc_train.sh (tools/kbench.py --what train), means per launch"), "kernels": {}}
+    # registers / occupancy of the shipped code object (what sets the issue ceiling): from the kernel trace
+    regs = {}
+    for f in glob.glob(os.path.join(src, "trace", "**", "*_kernel_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            name = r["Kernel_Name"].replace("void ", "").split("(")[0]
+            if "VGPR_Count" in r:
+                regs[name] = {"vgprs": int(r["VGPR_Count"]), "accum_vgprs": int(r.get("Accum_VGPR_Count", 0) or 0),
+                              "sgprs": int(r.get("SGPR_Count", 0) or 0), "lds_bytes": int(r.get("LDS_Block_Size", 0) or 0)}
     for k, d in agg.items():
         m = {c: sum(v) / len(v) for c, v in d.items()}
         e = {"counters": m}
@@ -55,6 +66,10 @@ def main():
                     e[key] = m[c] / m["SQ_WAVE_CYCLES"]
         if k in dur:
             e["kernel_us_profiled"] = sum(dur[k]) / len(dur[k])
+        if k in regs:
+            e.update(regs[k])
+            tot = regs[k]["vgprs"] + regs[k]["accum_vgprs"]
+            e["waves_per_simd"] = min(8, 512 // max(8, (tot + 7) // 8 * 8))
         out["kernels"][k] = e
     json.dump(out, open(dst, "w"), indent=1, sort_keys=True)
     print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "counters"} for k, v in out["kernels"].items()}, indent=1))
