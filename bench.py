@@ -390,6 +390,9 @@ def main():
     ap.add_argument("--per-scale-kernels", action="store_true",
                     help="round-1 path: one fused forward + one backward kernel per scale instead of the one-launch "
                          "training kernel")
+    ap.add_argument("--no-prologue", action="store_true",
+                    help="round-2 form of the photometric path: identity kernel + torch.randn + per-scale target statistics "
+                         "instead of the per-step prologue kernel (A/B)")
     ap.add_argument("--no-trainer-loop", action="store_true",
                     help="skip the second measurement (the DataLoader-fed trainer loop, reported as trainer_loop)")
     ap.add_argument("--float-loader", action="store_true",
@@ -454,6 +457,7 @@ def main():
     opt.channels_last = args.channels_last
     opt.fused_train = not args.per_scale_kernels
     opt.grad_comm, opt.bucket_mb = args.grad_comm, args.bucket_mb
+    opt.prologue = not args.no_prologue
     # MIOpen picks the tuned solvers from the shipped find-db in immediate mode already (fp32: same images/s as find
     # mode).  Find mode proper (--miopen-find) returns at once on a db hit but searches for minutes on a miss, so it
     # is never on by default; bf16 networks gain from it (a few more solvers are only reachable through find).

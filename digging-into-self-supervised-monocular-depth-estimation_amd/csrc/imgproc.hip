@@ -404,6 +404,30 @@ __global__ __launch_bounds__(256) void color_convert_kernel(const uint8_t *src, 
     dst[i] = (uint8_t)o.r; dst[n + i] = (uint8_t)o.g; dst[2 * n + i] = (uint8_t)o.b;
 }
 
+// ToTensor (kitti_mono.py:283,351): float32(byte) / 255 with the IEEE divide ToTensor's CPU division performs (a
+// multiplication by the rounded reciprocal -- what a generic tensor / scalar kernel does -- is off by one ulp for 126 of
+// the 256 byte values).  16 bytes per thread: one 16-byte load, four 16-byte stores; the tail byte by byte.
+__global__ __launch_bounds__(256) void to_tensor_kernel(const uint8_t *__restrict__ src, float *__restrict__ dst, size_t n)
+{
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 16;
+    if (i >= n) return;
+    if (i + 16 <= n && ((uintptr_t)(src + i) & 15) == 0) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(src + i);
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float4 o;
+            o.x = (float)(w[k] & 255u) / 255.0f;
+            o.y = (float)((w[k] >> 8) & 255u) / 255.0f;
+            o.z = (float)((w[k] >> 16) & 255u) / 255.0f;
+            o.w = (float)(w[k] >> 24) / 255.0f;
+            *reinterpret_cast<float4 *>(dst + i + 4 * k) = o;
+        }
+    } else {
+        for (size_t k = i; k < n && k < i + 16; ++k) dst[k] = (float)src[k] / 255.0f;
+    }
+}
+
 // ---- host side ----
 static double sinc_filter(double x)
 {
@@ -575,5 +599,14 @@ MDX_EXPORT int mdx_color_convert_u8(int mode, const uint8_t *src, uint8_t *dst, 
     if (npix == 0 || npix > ((size_t)1 << 31)) return MDX_ERR_BAD_SHAPE;
     hipLaunchKernelGGL(color_convert_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src,
                        dst, npix, mode);
+    return check_launch();
+}
+
+MDX_EXPORT int mdx_to_tensor_u8(const uint8_t *src, float *dst, size_t n, void *stream)
+{
+    if (!src || !dst) return MDX_ERR_NULL_POINTER;
+    if (n == 0 || n > ((size_t)1 << 36)) return MDX_ERR_BAD_SHAPE;
+    if (!aligned(dst, 16)) return MDX_ERR_MISALIGNED;
+    hipLaunchKernelGGL(to_tensor_kernel, dim3((unsigned)((n + 4095) / 4096)), dim3(256), 0, (hipStream_t)stream, src, dst, n);
     return check_launch();
 }

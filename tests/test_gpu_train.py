@@ -54,7 +54,7 @@ def test_train_kernel_vs_golden(G, case, rows):
     loss.backward()
     G.assert_close(loss, c["loss"], "loss", rel=1e-5)
     for s in range(c.n_scales):
-        G.assert_close(disps[s].grad, c["grad_disp_s%d" % s], "grad disp s%d" % s)
+        G.assert_close(disps[s].grad, c["grad_disp_s%d" % s], "grad disp s%d" % s, elem=1e-4)
     for f in c.sources_ids:
         if f != "s":
             G.assert_close(Ts[f].grad, c["grad_T_%s" % f], "grad T %s" % f)
@@ -77,7 +77,7 @@ def _synth_images(B, H, W, S, seed):
     return out, K, invK, Ts, rng
 
 
-def _oracle_case(G, B, H, W, S, seed, nscales=4, automask=True, grads=True, rows=0, white_noise=False):
+def _oracle_case(G, B, H, W, S, seed, nscales=4, automask=True, grads=True, rows=0, white_noise=False, grad_rel=1e-4):
     from oracle import oracle as orc
     colors, K, invK, Ts, rng = (_synth if white_noise else _synth_images)(B, H, W, S, seed=seed)
     hw = [(H >> s, W >> s) if H % 8 == 0 and W % 8 == 0 else (H, W) for s in range(nscales)]
@@ -105,10 +105,10 @@ def _oracle_case(G, B, H, W, S, seed, nscales=4, automask=True, grads=True, rows
         if grads:
             gd, gP = orc.photometric_bwd(disps_np[s], colors[0], colors[1:], invK, P_ref, ref["idx"], 1.0 / n,
                                          automask=automask)
-            G.assert_close(disps[s].grad, gd, "grad disp s%d" % s)
+            G.assert_close(disps[s].grad, gd, "grad disp s%d" % s, rel=grad_rel, elem=grad_rel)
             gP_ref = gP_ref + gP
     if grads:
-        G.assert_close(Pt.grad, gP_ref, "grad P")
+        G.assert_close(Pt.grad, gP_ref, "grad P", rel=grad_rel)
 
 
 @pytest.mark.parametrize("B,H,W,S,nscales,automask", [
@@ -125,13 +125,47 @@ def test_train_kernel_vs_oracle_full_size(G, B, H, W, S, nscales, automask):
 
 
 def test_train_kernel_vs_oracle_batch12(G):
-    """configs[1] at its full batch (12 x 192 x 640, S = 2): indices, to_optimise and sums of two scales."""
-    _oracle_case(G, 12, 192, 640, 2, seed=77, nscales=2, grads=False)
+    """configs[1] as bench.py runs it (12 x 192 x 640, S = 2, all four scales): indices, to_optimise, sums AND the
+    gradients -- d(P) is then the fixed-order sum over the 12 images' work items (train_finish_kernel)."""
+    _oracle_case(G, 12, 192, 640, 2, seed=77, nscales=4, grads=True)
 
 
 def test_train_kernel_vs_oracle_white_noise(G):
-    """White-noise colours (every window ill-conditioned): the per-pixel tensors and indices stay bit-exact."""
-    _oracle_case(G, 2, 192, 640, 2, seed=4323, nscales=4, grads=False, white_noise=True)
+    """White-noise colours (every window ill-conditioned): the per-pixel tensors and indices stay bit-exact; the
+    gradients, where any float32 evaluation carries ~1e-4 of rounding (tools/diag_grad_elementwise.py),
+    stay within 5e-4 of the oracle's in the max norm."""
+    _oracle_case(G, 2, 192, 640, 2, seed=4323, nscales=4, grads=True, white_noise=True, grad_rel=5e-4)
+
+
+@pytest.mark.parametrize("B,H,W,S,nscales,automask", [
+    (2, 192, 640, 2, 4, True),
+    (1, 192, 640, 3, 4, True),
+    (1, 100, 150, 2, 1, True),
+    (1, 192, 640, 2, 2, False),
+    (3, 64, 68, 1, 4, True),
+])
+def test_forward_only_form_equals_training_form(G, B, H, W, S, nscales, automask):
+    """Under torch.no_grad() (validation, model_train.py:75-79) the same launch runs without its gradient phase: loss
+    sums, indices, to_optimise and depth are those of the training form, bit for bit (and so the oracle's)."""
+    colors, K, invK, Ts, rng = _synth_images(B, H, W, S, seed=99 + S)
+    hw = [(H >> s, W >> s) if H % 8 == 0 and W % 8 == 0 else (H, W) for s in range(nscales)]
+    disps_np = [rng.rand(B, 1, h, w).astype(np.float32) for h, w in hw]
+    noises = [G.t(rng.randn(B, S, H, W).astype(np.float32)) for _ in range(nscales)] if automask else None
+    Kt = G.t(K)
+    P = torch.stack([G.F.compose_projection(Kt, G.t(T)) for T in Ts])
+    srcs = [G.t(x) for x in colors[1:]]
+    ident = G.F.identity_loss(G.t(colors[0]), srcs) if automask else None
+    args = (P, G.t(colors[0]), srcs, G.t(invK), ident, noises)
+    kw = dict(automask=automask, need_depth=True, need_to_opt=True)
+    a = G.F.photometric_train([G.t(x).requires_grad_(True) for x in disps_np], *args, **kw)
+    with torch.no_grad():
+        b = G.F.photometric_train([G.t(x).requires_grad_(True) for x in disps_np], *args, **kw)
+    c = G.F.photometric_train([G.t(x) for x in disps_np], *args, **kw)        # nothing requires a gradient
+    for o in (b, c):
+        assert not o["sums"].requires_grad
+        assert torch.equal(o["sums"], a["sums"].detach()) and torch.equal(o["depth"], a["depth"])
+        for s in range(nscales):
+            assert torch.equal(o["idx"][s], a["idx"][s]) and torch.equal(o["to_opt"][s], a["to_opt"][s])
 
 
 def test_train_kernel_matches_per_scale_kernels(G):

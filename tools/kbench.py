@@ -104,7 +104,7 @@ def main():
         fns = {"fwd": fwd, "bwd": bwd, "ident": ident_fn, "smooth": smooth}
         out = []
         for name in what:
-            if name == "train" or (name == "ident" and s):
+            if name in ("train", "pre") or (name == "ident" and s):
                 continue
             fn = fns[name]
             for _ in range(3):
@@ -117,6 +117,43 @@ def main():
             e1.synchronize()
             out.append("%s %.1f us" % (name, 1e3 * e0.elapsed_time(e1) / a.reps))
         print("scale %d: %s  (masked %.1f%%)" % (s, ", ".join(out), 100.0 * float((idx < S).float().mean())), flush=True)
+
+    if "pre" in what:
+        # the step's prologue (what the scales share: csrc/photo_prologue.hip) and the training kernel fed by it
+        nsc = a.nscales
+        disps = [x.clone().requires_grad_(True) for x in all_disps[:nsc]]
+        noises = [torch.randn(B, S, H, W, generator=g).to(dev) for _ in range(nsc)]
+        st = F.noise_state(dev, seed=1)
+
+        def timeit(fn):
+            for _ in range(3):
+                fn()
+            e0, e1 = ev(), ev()
+            e0.record()
+            for _ in range(a.reps):
+                fn()
+            e1.record()
+            e1.synchronize()
+            return 1e3 * e0.elapsed_time(e1) / a.reps
+        t_drawn = timeit(lambda: F.photometric_prologue(tgt, srcs, nsc, rng=st))
+        t_inj = timeit(lambda: F.photometric_prologue(tgt, srcs, nsc, noises=noises))
+        t_randn = timeit(lambda: torch.randn((nsc, B, S, H, W), device=dev))
+        pre = F.photometric_prologue(tgt, srcs, nsc, noises=noises)
+        F.TIMING = {"train": []}
+        t_call = timeit(lambda: F.photometric_train(disps, P, tgt, srcs, invK, pre=pre))
+        torch.cuda.synchronize()
+        tsum = F.timing_summary(F.TIMING)
+        F.TIMING = None
+        with torch.no_grad():
+            F.TIMING = {"eval": []}
+            t_eval = timeit(lambda: F.photometric_train(disps, P, tgt, srcs, invK, pre=pre))
+            torch.cuda.synchronize()
+            esum = F.timing_summary(F.TIMING)
+            F.TIMING = None
+        print("prologue: drawn noise %.1f us, injected noise %.1f us (torch.randn of the %d x [B,S,H,W] maps alone: %.1f us)"
+              % (t_drawn, t_inj, nsc, t_randn))
+        print("train_pre (%d scales): whole call %.1f us, fused kernel %.1f us; forward-only form: call %.1f us, kernel %.1f us"
+              % (nsc, t_call, tsum["train"][0], t_eval, esum["eval"][0]), flush=True)
 
     if "train" in what:
         nsc = a.nscales
