@@ -35,6 +35,16 @@ constexpr int SW = 60;   // output columns per wave (64 lanes - 2 x 2 halo lanes
 #ifndef MDX_TRAIN_OPAQUE_HIST
 #define MDX_TRAIN_OPAQUE_HIST 1
 #endif
+#ifndef MDX_TRAIN_LAZY_COEF
+#define MDX_TRAIN_LAZY_COEF 1     // SSIM gradient coefficients of a frame only in waves where it can be some lane's arg-min
+#endif
+#ifndef MDX_TRAIN_WAVE_UNIFORM
+#define MDX_TRAIN_WAVE_UNIFORM 0  // per-wave (not per-lane) choice of the u/(W-1), v/(H-1) division form and of the corner border
+                                  // handling: ~70 fewer VALU instructions per step on paper, +1 % time measured (tools/ab_bench2.sh)
+#endif
+#ifndef MDX_EVAL_WAVES
+#define MDX_EVAL_WAVES 5          // waves per SIMD of the forward-only form for S <= 2 (96 VGPRs)
+#endif
 #ifndef MDX_TRAIN_LOSS_LDS
 #define MDX_TRAIN_LOSS_LDS 1      // loss partial of a lane: LDS cell + ds_add_f32 (1) or a float register (0)
 #endif
@@ -171,6 +181,46 @@ MDX_DEV QuotRcp quot_rcp(float n, float d)
 // subtraction, formed here once per pixel -- or once per STEP by photo_prologue.hip)
 struct TStat { float mu, mu2, sig_y; };
 
+// The same in two halves (MDX_TRAIN_LAZY_COEF): the value now -- keeping what the coefficients need -- and the coefficient
+// triplet later, only in waves where the frame can still be some lane's arg-min.
+struct SsimMid { float A1, A2, B1, B2, q, inv_d, mu_x, raw; };
+
+MDX_DEV float ssim_value_mid(const SsimTerms &s, const TStat &t, SsimMid &m)
+{
+    const float mxx = s.mu_x * s.mu_x;
+    const float mxy = s.mu_x * t.mu;
+    const float sig_x = s.ex2 - mxx;
+    const float sig_xy = s.exy - mxy;
+    float a = 2.0f * s.mu_x;
+    a = a * t.mu;
+    m.A1 = a + MDX_C1;
+    float A2 = 2.0f * sig_xy;
+    m.A2 = A2 + MDX_C2;
+    const float n = m.A1 * m.A2;
+    m.B1 = (mxx + t.mu2) + MDX_C1;
+    m.B2 = (sig_x + t.sig_y) + MDX_C2;
+    const float d = m.B1 * m.B2;
+    const QuotRcp qr = quot_rcp(n, d);
+    m.q = qr.q;
+    m.inv_d = qr.r;
+    m.mu_x = s.mu_x;
+    m.raw = (1.0f - qr.q) / 2.0f;
+    return clamp01(m.raw);
+}
+
+MDX_DEV SsimGrad ssim_coef_mid(const SsimMid &m, const TStat &t, float gscale)
+{
+    const float Ln = -0.5f * m.inv_d, Ld = 0.5f * m.q * m.inv_d;
+    const float dA1 = Ln * m.A2, dA2 = Ln * m.A1, dB1 = Ld * m.B2, dB2 = Ld * m.B1;
+    const bool pass = m.raw >= 0.f && m.raw <= 1.f;   // clamp passes the gradient on the closed interval
+    const float gs = pass ? gscale : 0.f;
+    SsimGrad g;
+    g.alpha = gs * 2.0f * (t.mu * (dA1 - dA2) + m.mu_x * (dB1 - dB2));
+    g.beta = gs * dB2;
+    g.gamma = gs * 2.0f * dA2;
+    return g;
+}
+
 MDX_DEV SsimBoth ssim_both(const SsimTerms &s, const TStat &t, float gscale)
 {
     const float mxx = s.mu_x * s.mu_x;
@@ -215,7 +265,7 @@ MDX_DEV SsimBoth ssim_both(const SsimTerms &s, const TStat &t, float gscale)
 // on real data: z = q2 + 1e-7 is 0 or >= 2^-47 in magnitude).
 MDX_DEV bool wave_all_normal(float v)
 {
-    return __builtin_amdgcn_ballot_w64(__builtin_amdgcn_class(v, 0x2F7)) == 0;    // anything but +-normal
+    return __builtin_amdgcn_ballot_w64(__builtin_amdgcn_classf(v, 0x2F7)) == 0;   // anything but +-normal (classf: the float form)
 }
 MDX_DEV float refined_rcp(float d)
 {
@@ -253,11 +303,36 @@ MDX_DEV Proj project_point_train(const float *__restrict__ P, float X0, float X1
         p.u = q[0] / p.z;
         p.v = q[1] / p.z;
     }
-    const float nx = div_norm(p.u, nd.w);
-    const float ny = div_norm(p.v, nd.h);
+    // u / (W-1), v / (H-1): div_norm() picks per LANE between the verified 3-instruction constant division and the IEEE
+    // divide -- as a select, so both run.  Here the choice is made once per wave (a lane outside the verified range, i.e.
+    // |x| <= 1e-30 or >= 3e38, sends the wave through `/`): the 2 x 11 instructions of the unused divides are gone.
+    float nx, ny;
+    const float au = fabsf(p.u), av = fabsf(p.v);
+    const bool fast_ok = nd.w.fast && nd.h.fast && au > 1e-30f && au < 3.0e38f && av > 1e-30f && av < 3.0e38f;
+    if (MDX_TRAIN_WAVE_UNIFORM && __builtin_amdgcn_ballot_w64(!fast_ok) == 0) {
+        nx = div_by_const(p.u, nd.w.b, nd.w.r);
+        ny = div_by_const(p.v, nd.h.b, nd.h.r);
+    } else {
+        nx = div_norm(p.u, nd.w);
+        ny = div_norm(p.v, nd.h);
+    }
     p.gx = (nx - 0.5f) * 2.0f;
     p.gy = (ny - 0.5f) * 2.0f;
     return p;
+}
+
+// load_corners() (mdx_device.hpp) with the border handling decided per wave: a tap on the image's last column / last row
+// needs the pair shifted / the lower pair zeroed (four selects per channel); only waves that hold such a tap pay for them.
+MDX_DEV Corners load_corners_train(const float *__restrict__ img, int H, int W, const Tap &t, bool border_wave)
+{
+    if (!MDX_TRAIN_WAVE_UNIFORM || border_wave) return load_corners(img, H, W, t);
+    const unsigned o0 = (unsigned)(t.y0 * W + t.x0) * 4u, o1 = o0 + (unsigned)W * 4u;
+    const char *base = reinterpret_cast<const char *>(img);
+    const float2_a4 top = *reinterpret_cast<const float2_a4 *>(base + o0);
+    const float2_a4 bot = *reinterpret_cast<const float2_a4 *>(base + o1);
+    Corners c;
+    c.nw = top.x; c.ne = top.y; c.sw = bot.x; c.se = bot.y;
+    return c;
 }
 
 // geom_from_disp() (photo_common.hpp) likewise
@@ -621,10 +696,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
                 tp[f] = make_tap(pr[f].gx, pr[f].gy, H, W);
             }
 #pragma unroll
-            for (int f = 0; f < S; ++f)
+            for (int f = 0; f < S; ++f) {
+                // does any lane of the wave tap the last column or the last row of this frame?  (wave-uniform)
+                const bool border_wave = __builtin_amdgcn_ballot_w64(tp[f].x0 >= W - 1 || tp[f].y0 >= H - 1) != 0;
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
-                    cn[f][c] = load_corners(a.src.img[f] + ((size_t)b * 3 + c) * HW, H, W, tp[f]);
+                    cn[f][c] = load_corners_train(a.src.img[f] + ((size_t)b * 3 + c) * HW, H, W, tp[f], border_wave);
+            }
             prefetch_warp_row(wr + 1);
 #if MDX_TRAIN_DEFER_GUP
             if constexpr (GRAD) {
@@ -697,13 +775,33 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
             }
             // reprojection channels in order; the coefficient triplets of the best reprojection frame so far are
             // kept as the candidate (strict <: torch.min's first-minimum rule among equal values)
+            // the best identity channel first (concat [ident + 1e-5*noise, reproj], processor.py:194-204): a reprojection
+            // frame that does not beat it in any lane of the wave needs no gradient coefficients
+            float bid = 0.f;
+            int fi = 0;
+            if (automask) {
+                if constexpr (PRE) {
+                    bid = __builtin_bit_cast(float, pf_bf.x);
+                    fi = (int)pf_bf.y;
+                } else {
+#pragma unroll
+                    for (int f = 0; f < S; ++f) {
+                        const float tn = 1e-5f * pf_nz[f];
+                        const float v = pf_id[f] + tn;
+                        if (f == 0 || v < bid) { bid = v; fi = f; }
+                    }
+                }
+            }
             float best_r = 0.f;
             int fr = 0;
-            float cand[3][3];
+            float cand[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
 #pragma unroll
             for (int f = 0; f < S; ++f) {
                 float ss[3], ad[3];
                 SsimGrad sg[3];
+#if MDX_TRAIN_LAZY_COEF
+                SsimMid mid[3];
+#endif
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     float q[3][3], o[3];
@@ -718,9 +816,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
                     SsimTerms st;
                     st.mu_x = o[0]; st.ex2 = o[1]; st.exy = o[2];
                     if constexpr (GRAD) {
+#if MDX_TRAIN_LAZY_COEF
+                        ss[c] = ssim_value_mid(st, ts[c], mid[c]);
+#else
                         const SsimBoth sb = ssim_both(st, ts[c], 0.85f / 3.0f);
                         ss[c] = sb.val;
                         sg[c] = sb.g;
+#endif
                     } else {
                         ss[c] = ssim_val(st, ts[c]);
                     }
@@ -731,31 +833,36 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
                 best_r = better ? rl : best_r;
                 fr = better ? f : fr;
                 if constexpr (GRAD) {
+#if MDX_TRAIN_LAZY_COEF
+                    // the frame can end as a lane's arg-min only where it beats the frames before it AND the best identity
+                    // channel (later frames can only take lanes away); where it ends as the arg-min, `better` held here, so
+                    // the candidate selected below is the one the gradient phase needs.  Wave-uniform skip otherwise: in
+                    // auto-masked regions (static scene, sky) no frame's coefficients are formed at all.
+                    const bool can_win = better && ssim_lane && (!automask || rl < bid);
+                    if (__builtin_amdgcn_ballot_w64(can_win) != 0) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) sg[c] = ssim_coef_mid(mid[c], ts[c], 0.85f / 3.0f);
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            cand[c][0] = better ? sg[c].alpha : cand[c][0];
+                            cand[c][1] = better ? sg[c].beta : cand[c][1];
+                            cand[c][2] = better ? sg[c].gamma : cand[c][2];
+                        }
+                    }
+#else
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         cand[c][0] = better ? sg[c].alpha : cand[c][0];
                         cand[c][1] = better ? sg[c].beta : cand[c][1];
                         cand[c][2] = better ? sg[c].gamma : cand[c][2];
                     }
+#endif
                 }
             }
             // concat [ident + 1e-5*noise, reproj] and torch.min's first-minimum rule (processor.py:194-204)
             float best = best_r;
             int bi = fr;
             if (automask) {
-                float bid = 0.f;
-                int fi = 0;
-                if constexpr (PRE) {
-                    bid = __builtin_bit_cast(float, pf_bf.x);
-                    fi = (int)pf_bf.y;
-                } else {
-#pragma unroll
-                    for (int f = 0; f < S; ++f) {
-                        const float tn = 1e-5f * pf_nz[f];
-                        const float v = pf_id[f] + tn;
-                        if (f == 0 || v < bid) { bid = v; fi = f; }
-                    }
-                }
                 const bool reproj_wins = best_r < bid;     // identity channels come first: ties go to them
                 best = reproj_wins ? best_r : bid;
                 bi = reproj_wins ? S + fr : fi;
@@ -1145,8 +1252,8 @@ struct TrainPlan {
 // Chunk schedule of a column of H rows.  rows_per_chunk > 0: uniform chunks of that many rows (tests, sweeps).
 // 0: guided -- about 60 % of the rows in large chunks (4 halo rows per chunk cost little), 25 % in chunks half as
 // tall, the rest in small ones that end the launch without a long ragged tail (a work item is one wave walking
-// rows + 4 steps; their cost also varies with the auto-mask pattern).  MDX_TRAIN_SCHEDULE="r1,f1,r2,f2,r3" overrides
-// (rows of the levels, fractions of H in levels 1 and 2) for tuning.
+// rows + 4 steps; their cost also varies with the auto-mask pattern).  In -DMDX_DEV_SWITCHES builds
+// MDX_TRAIN_SCHEDULE="r1,f1,r2,f2,r3" overrides (rows of the levels, fractions of H in levels 1 and 2) for tuning.
 static void choose_levels(const mdx_train_desc *d, TrainPlan &p)
 {
     const int H = d->H;
@@ -1159,6 +1266,7 @@ static void choose_levels(const mdx_train_desc *d, TrainPlan &p)
         r[0] = H >= 160 ? 40 : (H >= 64 ? 24 : 16);
         r[1] = r[0] / 2;
         r[2] = r[1] / 2 > 4 ? r[1] / 2 : 4;
+#ifdef MDX_DEV_SWITCHES      // sweeps of the builder only (MDX_BUILD_DEFINES=-DMDX_DEV_SWITCHES): the shipped library never reads the environment
         if (const char *e = getenv("MDX_TRAIN_SCHEDULE")) {
             int a0, a1, a2;
             double g1, g2;
@@ -1167,6 +1275,7 @@ static void choose_levels(const mdx_train_desc *d, TrainPlan &p)
                 r[0] = a0; r[1] = a1; r[2] = a2; f1 = g1; f2 = g2;
             }
         }
+#endif
     }
     int row = 0, k = 0;
     for (int l = 0; l < 3; ++l) {
