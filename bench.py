@@ -213,20 +213,24 @@ def roofline_blocks(args, opt, frame_ids, tsum):
         same_shape = pmc.get("shape") == [args.batch, opt.height, opt.width, nS, nsc]
         if ent and same_shape and pmc.get("lib_sha16") == so:
             traffic = ent.get("traffic_bytes")
-            issue = {kk: ent[kk] for kk in ("valu_wave_insts", "valu_issue_us", "wait_any_frac", "wait_inst_frac",
-                                            "active_frac", "kernel_us_profiled", "vgprs", "waves_per_simd") if kk in ent}
+            issue = {kk: ent[kk] for kk in ("valu_wave_insts", "valu_issue_us", "valu_busy_us", "wait_any_frac",
+                                            "wait_inst_frac", "active_frac", "kernel_us_profiled") if kk in ent}
             issue["source"] = pmc.get("source")
     except (OSError, ValueError, KeyError):
         pass
     launch_us = 1e3 * k[dom]["ms"]
     # VALU-issue roofline of the same launch: wave-instructions x 2 cycles / (1024 SIMDs x 2.4 GHz) over its duration
     valu_frac = (issue["valu_issue_us"] / launch_us) if issue and issue.get("valu_issue_us") else None
+    # share of the launch during which the SIMDs' vector ALUs are occupied (SQ_ACTIVE_INST_VALU, 4 cycles per unit): the
+    # roof this kernel actually sits under -- ~1.0 means every VALU instruction removed shortens the launch in proportion
+    valu_busy = (issue["valu_busy_us"] / issue["kernel_us_profiled"]) if issue and issue.get("valu_busy_us") and issue.get("kernel_us_profiled") else None
     hbm_frac = k[dom]["GBs"] / HBM_PEAK_GBS
     out = {"roofline": {"kernel": k[dom]["name"],
                         "bound": "hbm",        # the roofline `frac` is quoted against (BASELINE.json: HBM roofline of this kernel)
-                        "limiter": (None if valu_frac is None else ("valu-issue" if valu_frac > hbm_frac else "hbm")),
+                        "limiter": (None if valu_frac is None else ("valu" if max(valu_frac, valu_busy or 0.0) > hbm_frac else "hbm")),
                         "achieved": k[dom]["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": hbm_frac, "valu_issue_frac": valu_frac, "traffic": traffic, "issue": issue,
+                        "frac": hbm_frac, "valu_issue_frac": valu_frac, "valu_busy_frac": valu_busy, "traffic": traffic,
+                        "issue": issue,
                         "launch_us": launch_us, "alg_bytes_per_launch": k[dom]["bytes"],
                         "launches_timed": k[dom]["launches"],
                         "alg_bytes": "SURVEY 8d per scale (fwd: B*H*W*(12+12S+1)+B*h*w*4, bwd: ...+B*h*w*8), summed "

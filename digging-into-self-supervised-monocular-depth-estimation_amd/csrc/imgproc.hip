@@ -27,12 +27,11 @@ constexpr int RS_BITS = 32 - 8 - 2;          // Resample.c PRECISION_BITS
 struct ResampleJob : mdx_resample_job {
     int vec4;                 // the vertical pass may use dword accesses (alignment and row length checked on the host)
     int h_taps;               // horizontal pass: 0 = lanes along the columns, C > 0 = resample_h_taps_kernel<C>
-    int h_window;             // lanes along the columns: 0 = one gather per tap, KT > 0 = window form evaluating KT taps
-                              // (13 / 16: three 16-byte loads per row, 26: five, 49 / 53: ten)
+    int h_window;             // lanes along the columns: 0 = one gather per tap and row, KT > 0 = staged through LDS,
+                              // KT taps evaluated (13, 16, 26, 49, 53)
 };
 struct ResampleJobs {
     ResampleJob j[MDX_IMG_JOBS];
-    int y_block0;             // resample_h_kernel: first row block of the launch (window-only batches launch the last ones only)
 };
 struct JitterJobs {
     mdx_jitter_job j[MDX_IMG_JOBS];
@@ -120,76 +119,6 @@ static __device__ __forceinline__ void resample_h_body(const ResampleJob &J, int
     }
 }
 
-// WINDOW form of the horizontal pass (round 3).  The column form above issues one 4-byte gather per tap and row: 13 load
-// instructions per output for the 640-column scale, and the texture-address path -- 64 lanes each fetching its own unaligned
-// dword, ~18 CU-cycles per instruction -- was what bounded it (profiles/r02_imgproc_kernel_pmc.txt).  A column's taps are
-// CONTIGUOUS source bytes (3 * ksize of them, 39 for 13 taps): here a lane fetches its whole window with NL unaligned
-// 16-byte loads (3 instead of 13 instructions, and a 16-byte access moves through the address path at full width) and picks
-// the bytes out of registers at positions known at compile time (v_bfe_u32 + v_mad_i32_i24 per byte and tap).  The window
-// starts at the column's first tap, so tap t sits at bytes 3t .. 3t+2 whatever the column; flipped images read the window
-// of the mirrored taps and take the weights in reverse.  The weights live in registers for the ROWS rows a lane handles.
-// A window may run past its row's last pixel (the table's weights are zero there): the bytes then come from the next row
-// of the same image; only for an image's LAST row the caller checks that the read stays inside the row pitch and falls
-// back to the column form otherwise (wave-uniform).
-template <int NL, int KT, int ROWS, bool FLIP>
-static __device__ __forceinline__ void resample_h_window(const ResampleJob &J, int xo, int y0, bool ok, int lane)
-{
-    static_assert(3 * KT <= 16 * NL, "the window must hold the taps");
-    const int xmin = J.xbounds[2 * xo], n = J.xbounds[2 * xo + 1];
-    const int *k = J.xkk + xo;
-    const int last = J.in_w - 1;
-    const int px0 = FLIP ? last - xmin - (n - 1) : xmin;
-    int w[KT];
-#pragma unroll
-    for (int p = 0; p < KT; ++p) {
-        const int t = FLIP ? n - 1 - p : p;
-        w[p] = p < n ? k[(size_t)t * J.out_w] : 0;
-    }
-    const size_t plane = (size_t)J.in_h * J.out_w;
-#pragma unroll 1
-    for (int r0 = 0; r0 < HR; r0 += ROWS) {
-        unsigned d[ROWS][4 * NL];
-#pragma unroll
-        for (int r = 0; r < ROWS; ++r) {                                       // every load of the group before the first use
-            const int y = min(y0 + r0 + r, J.in_h - 1);
-            const uint8_t *base = J.src + (size_t)y * J.in_stride + 3u * (unsigned)px0;
-#pragma unroll
-            for (int q = 0; q < NL; ++q) {
-                uint4 v;
-                __builtin_memcpy(&v, base + 16 * q, 16);                       // one unaligned global_load_dwordx4
-                d[r][4 * q] = v.x; d[r][4 * q + 1] = v.y; d[r][4 * q + 2] = v.z; d[r][4 * q + 3] = v.w;
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < ROWS; ++r) {
-            int s0 = 1 << (RS_BITS - 1), s1 = s0, s2 = s0;
-#pragma unroll
-            for (int p = 0; p < KT; ++p) {
-                const int b = 3 * p;
-                s0 += __mul24((int)((d[r][b >> 2] >> (8 * (b & 3))) & 255u), w[p]);
-                s1 += __mul24((int)((d[r][(b + 1) >> 2] >> (8 * ((b + 1) & 3))) & 255u), w[p]);
-                s2 += __mul24((int)((d[r][(b + 2) >> 2] >> (8 * ((b + 2) & 3))) & 255u), w[p]);
-            }
-            const int y = min(y0 + r0 + r, J.in_h - 1);
-            const bool row_ok = ok && y0 + r0 + r < J.in_h;
-            const size_t o = (size_t)y * J.out_w + xo;
-            store_bytes_packed(J.inter + o, clip8(s0), J.vec4 != 0, row_ok, lane);
-            store_bytes_packed(J.inter + plane + o, clip8(s1), J.vec4 != 0, row_ok, lane);
-            store_bytes_packed(J.inter + 2 * plane + o, clip8(s2), J.vec4 != 0, row_ok, lane);
-        }
-    }
-}
-
-// may the wave (columns xo0..xl, rows y0..y0+HR-1) of a window-form job read its windows?  Always, unless it holds the
-// image's last row and the furthest window start + the window's bytes would leave that row's pitch.  Wave-uniform.
-static __device__ __forceinline__ bool window_safe(const ResampleJob &J, int xo0, int xl, int y0)
-{
-    if (y0 + HR < J.in_h) return true;
-    const int nl16 = J.h_window <= 16 ? 48 : (J.h_window <= 26 ? 80 : 160);
-    const int xf = J.flip ? J.in_w - 1 - J.xbounds[2 * xo0] - (J.xbounds[2 * xo0 + 1] - 1) : J.xbounds[2 * xl];
-    return 3 * max(xf, 0) + nl16 <= J.in_stride;
-}
-
 // Taps come straight from global memory (L1 / L2 serve the overlap of neighbouring columns and tiles).  An LDS-staged
 // form (row segments copied with 16-byte loads, taps as unaligned ds_read_b32) was measured at 166 us against 60 us for
 // this one on 32 KITTI frames: lanes 6 bytes apart reading unaligned dwords serialise on the LDS banks.
@@ -201,14 +130,14 @@ __global__ __launch_bounds__(256) void resample_h_kernel(ResampleJobs jobs)
     const int xo0 = blockIdx.x * 64;
     // the wave index as a scalar: taken from threadIdx.x alone the compiler treats the row addresses as lane-varying
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int y0 = ((blockIdx.y + jobs.y_block0) * 4 + wave) * HR;
+    const int y0 = (blockIdx.y * 4 + wave) * HR;
     if (xo0 >= J.out_w || y0 >= J.in_h) return;                      // wave-uniform: the packed stores need whole waves
     const bool ok = xo0 + lane < J.out_w;
     const int xo = min(xo0 + lane, J.out_w - 1);
     // does any lane tap the last source pixel?  (bounds are monotonic: the last column reaches furthest)
     const int xl = min(xo0 + 63, J.out_w - 1);
     const bool edge = J.flip ? J.xbounds[2 * xo0] == 0 : J.xbounds[2 * xl] + J.xbounds[2 * xl + 1] == J.in_w;
-    if (J.h_window && window_safe(J, xo0, xl, y0)) return;           // this wave runs in resample_h_window_kernel
+    if (J.h_window) return;                                          // this job runs in resample_h_staged_kernel
     if (J.flip) {
         if (edge) resample_h_body<true, true>(J, xo, y0, ok, lane);
         else resample_h_body<true, false>(J, xo, y0, ok, lane);
@@ -218,24 +147,138 @@ __global__ __launch_bounds__(256) void resample_h_kernel(ResampleJobs jobs)
     }
 }
 
-// Window-form jobs: one kernel per window size (its registers set the occupancy); the waves whose window could leave the
-// row pitch on an image's last row are left to resample_h_kernel (window_safe, the same test on both sides).
-template <int NL, int KT, int ROWS>
-__global__ __launch_bounds__(256) void resample_h_window_kernel(ResampleJobs jobs)
+// STAGED form of the horizontal pass (round 3).  The gather form above issues one 4-byte load per tap and row -- 13 load
+// instructions per output for the 640-column scale -- and the address path, 64 lanes each fetching its own unaligned
+// dword at a ~6-byte stride, is what bounds it (~18 CU-cycles per instruction, profiles/r02_imgproc_kernel_pmc.txt; a form
+// that fetched each lane's 39-byte window with three unaligned 16-byte loads measured the same 57 us: the path is paced by
+// the lanes' scattered addresses, not by the instruction count).  Here a block of 64 output columns x 16 rows first copies
+// the source bytes its columns touch -- ONE contiguous span per row, ~420 bytes for the 640-column scale -- into LDS with
+// coalesced 16-byte loads (each source byte crosses the address path once), then every lane reads its taps from LDS as
+// BYTES (ds_read_u8 with the tap's offset as the instruction's immediate: no address arithmetic, no extraction, no
+// alignment issue -- the first LDS version of round 2 read unaligned dwords and serialised on the banks) and multiplies.
+// A span that runs past the image's last byte is completed with zeros (those taps' weights are zero): nothing is read
+// beyond the image's rows.
+// Flipped images stage the mirrored span and take the weights in reverse.  KT = taps evaluated (>= the filter's ksize).
+// Measured (32 frames 1242x375 -> 640 columns): 47.7 us against 58 us for the gather form.  What bounds it now is the LDS:
+// 64 lanes 6 bytes apart touch ~93 different dwords per read instruction -- three per bank -- so every ds_read_u8 takes
+// ~three passes (156 of them per wave).  Reading dwords instead and picking the bytes apart costs two VALU instructions
+// per byte and tap again (the compiler's own choice for the non-volatile form: 52 us); a form that fetched each lane's
+// window with three unaligned 16-byte GLOBAL loads measured 57 us.  All three sit within 20 % of each other: the pass is
+// a 6-byte-stride gather whichever way it is served.
+constexpr int HS_ROWS = 16;                 // rows per block = 4 waves x HR
+typedef const volatile uint8_t __attribute__((address_space(3))) *lds_cv_u8;
+// a * b + c with a, b in 24 bits (|weight| < 2^22, byte < 2^8): ONE instruction.  Written as asm because the compiler
+// forms v_mad_i32_i24 from __mul24 + add in a few places only and leaves a v_mul_i32_i24 + v_add pair elsewhere.
+static __device__ __forceinline__ int mad24(int a, int b, int c)
 {
-    const ResampleJob &J = jobs.j[blockIdx.z];
-    if (J.h_window != KT) return;
-    const int lane = threadIdx.x & 63;
-    const int xo0 = blockIdx.x * 64;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int y0 = (blockIdx.y * 4 + wave) * HR;
-    if (xo0 >= J.out_w || y0 >= J.in_h) return;
+    int d;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+template <int KT, bool FLIP>
+static __device__ __forceinline__ void resample_h_staged(const ResampleJob &J, uint8_t *lds, int pitch_max)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xo0 = blockIdx.x * 64, yb = blockIdx.y * HS_ROWS;
     const int xl = min(xo0 + 63, J.out_w - 1);
-    if (!window_safe(J, xo0, xl, y0)) return;
+    const int last = J.in_w - 1;
+    // first / last source pixel the block's columns tap (bounds are monotonic in the column)
+    const int lo_min = J.xbounds[2 * xo0], hi_max = J.xbounds[2 * xl] + J.xbounds[2 * xl + 1] - 1;
+    const int px_lo = FLIP ? last - hi_max : lo_min, px_hi = FLIP ? last - lo_min : hi_max;
+    const int a0 = (3 * px_lo) & ~15;
+    const int nch = min((3 * px_hi + 3 - a0 + 15) >> 4, pitch_max >> 4);
+    const int pitch = nch << 4;
+    const unsigned total = (unsigned)J.in_h * (unsigned)J.in_stride;          // bytes of the image's rows (its slot may be larger)
+    for (int i = tid; i < HS_ROWS * nch; i += 256) {
+        const int r = i / nch, ch = i - r * nch;
+        const int y = min(yb + r, J.in_h - 1);
+        const unsigned off = (unsigned)y * (unsigned)J.in_stride + (unsigned)(a0 + 16 * ch);
+        u32x4_t v;
+        if (off + 16u <= total) {
+            __builtin_memcpy(&v, J.src + off, 16);                             // one unaligned global_load_dwordx4
+        } else {                                                               // the image's last bytes: nothing past them is read
+            uint8_t b[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) b[e] = off + e < total ? J.src[off + e] : 0;
+            __builtin_memcpy(&v, b, 16);
+        }
+        *reinterpret_cast<u32x4_t *>(lds + r * pitch + 16 * ch) = v;
+    }
     const bool ok = xo0 + lane < J.out_w;
     const int xo = min(xo0 + lane, J.out_w - 1);
-    if (J.flip) resample_h_window<NL, KT, ROWS, true>(J, xo, y0, ok, lane);
-    else resample_h_window<NL, KT, ROWS, false>(J, xo, y0, ok, lane);
+    const int xmin = J.xbounds[2 * xo], n = J.xbounds[2 * xo + 1];
+    const int *k = J.xkk + xo;
+    const int px0 = FLIP ? last - xmin - (n - 1) : xmin;
+    int w[KT];
+#pragma unroll
+    for (int p = 0; p < KT; ++p) {
+        const int t = FLIP ? n - 1 - p : p;
+        w[p] = p < n ? k[(size_t)t * J.out_w] : 0;
+    }
+    __syncthreads();
+    const size_t plane = (size_t)J.in_h * J.out_w;
+    const uint8_t *col = lds + (3 * px0 - a0);
+    // results leave through LDS too when the block's 64 columns are whole and 16-byte aligned in the output rows: the
+    // 3 x 16 row segments of 64 bytes go out as 192 16-byte stores (3 store instructions per block instead of 48 that
+    // each write 16 scattered dwords)
+    uint8_t *s_out = lds + HS_ROWS * pitch_max;                                // [3][HS_ROWS][64]
+    const bool wide_out = J.vec4 && (J.out_w & 15) == 0 && xo0 + 64 <= J.out_w && (((size_t)J.inter) & 15) == 0 &&
+                          (plane & 15) == 0;
+#pragma unroll
+    for (int r = 0; r < HR; ++r) {
+        const int row = wave * HR + r;
+        // volatile: one ds_read_u8 per tap byte, as written.  Left alone the compiler merges the bytes into unaligned
+        // 16-byte LDS reads and picks them apart with v_mul_i32_i24_sdwa + v_add (two VALU instructions per byte and tap,
+        // ~900 per wave: the kernel then runs at the VALU's pace, 52 us -- no faster than the gather form); a byte read
+        // delivers the operand ready for ONE v_mad_i32_i24
+        const lds_cv_u8 q = (lds_cv_u8)(col + row * pitch);
+        int s0 = 1 << (RS_BITS - 1), s1 = s0, s2 = s0;
+        int bytes[3 * KT];
+#pragma unroll
+        for (int e = 0; e < 3 * KT; ++e) bytes[e] = (int)q[e];
+#pragma unroll
+        for (int p = 0; p < KT; ++p) {
+            s0 = mad24(bytes[3 * p], w[p], s0);
+            s1 = mad24(bytes[3 * p + 1], w[p], s1);
+            s2 = mad24(bytes[3 * p + 2], w[p], s2);
+        }
+        if (wide_out) {
+            s_out[(0 * HS_ROWS + row) * 64 + lane] = clip8(s0);
+            s_out[(1 * HS_ROWS + row) * 64 + lane] = clip8(s1);
+            s_out[(2 * HS_ROWS + row) * 64 + lane] = clip8(s2);
+        } else {
+            const int y = min(yb + row, J.in_h - 1);
+            const bool row_ok = ok && yb + row < J.in_h;
+            const size_t o = (size_t)y * J.out_w + xo;
+            store_bytes_packed(J.inter + o, clip8(s0), J.vec4 != 0, row_ok, lane);
+            store_bytes_packed(J.inter + plane + o, clip8(s1), J.vec4 != 0, row_ok, lane);
+            store_bytes_packed(J.inter + 2 * plane + o, clip8(s2), J.vec4 != 0, row_ok, lane);
+        }
+    }
+    if (wide_out) {
+        __syncthreads();
+        if (tid < 3 * HS_ROWS * 4) {
+            const int seg = tid >> 2, quarter = tid & 3;                       // seg = plane * HS_ROWS + row
+            const int pl = seg / HS_ROWS, row = seg - pl * HS_ROWS;
+            if (yb + row < J.in_h)
+                *reinterpret_cast<u32x4_t *>(J.inter + pl * plane + (size_t)(yb + row) * J.out_w + xo0 + 16 * quarter) =
+                    *reinterpret_cast<const u32x4_t *>(s_out + seg * 64 + 16 * quarter);
+        }
+    }
+}
+
+template <int KT>
+__global__ __launch_bounds__(256) void resample_h_staged_kernel(ResampleJobs jobs, int pitch_max)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_span[];
+    const ResampleJob &J = jobs.j[blockIdx.z];
+    if (J.h_window != KT) return;
+    if ((int)blockIdx.x * 64 >= J.out_w || (int)blockIdx.y * HS_ROWS >= J.in_h) return;      // block-uniform
+    if (J.flip) resample_h_staged<KT, true>(J, s_span, pitch_max);
+    else resample_h_staged<KT, false>(J, s_span, pitch_max);
 }
 
 // Horizontal pass for strong reductions (65..128 taps: the 80-column scale of a 1242-wide frame has 95).  With lanes along the
@@ -615,13 +658,15 @@ MDX_EXPORT int mdx_resample_lanczos_u8(const mdx_resample_job *jobs, int njobs, 
         const int n = njobs - first < MDX_IMG_JOBS ? njobs - first : MDX_IMG_JOBS;
         ResampleJobs a;
         memset(&a, 0, sizeof(a));
-        int max_in_h = 0, min_in_h = 1 << 30, max_out_w = 0, max_out_h = 0, n4 = 0, n_cols = 0, n_gather = 0, cols_out_w = 0, taps_out_w = 0;
+        int max_in_h = 0, min_in_h = 1 << 30, max_out_w = 0, max_out_h = 0, n4 = 0, n_gather = 0, cols_out_w = 0, taps_out_w = 0;
         unsigned taps_used = 0, win_used = 0;
+        int win_pitch[5] = {0, 0, 0, 0, 0};
 #ifdef MDX_DEV_SWITCHES      // A/B builds only (build.py MDX_BUILD_DEFINES=-DMDX_DEV_SWITCHES): the shipped library never reads the environment
         const bool force_cols = getenv("MDX_RESAMPLE_COLUMNS") != nullptr;
         const bool force_gather = getenv("MDX_RESAMPLE_GATHER") != nullptr;
+        const bool force_staged = getenv("MDX_RESAMPLE_STAGED") != nullptr;
 #else
-        const bool force_cols = false, force_gather = false;
+        const bool force_cols = false, force_gather = false, force_staged = false;
 #endif
         for (int i = 0; i < n; ++i) {
             static_cast<mdx_resample_job &>(a.j[i]) = jobs[first + i];
@@ -633,16 +678,27 @@ MDX_EXPORT int mdx_resample_lanczos_u8(const mdx_resample_job *jobs, int njobs, 
             // 49 taps 36 / 43 us, 95 taps 82 / 31 us): chunked taps for 65..128 taps, lanes along the columns otherwise
             const int ks = J.xksize;
             J.h_taps = force_cols || ks <= 64 || ks > 128 ? 0 : (ks <= 96 ? 6 : 8);
-            // window form: the filter's taps fit NL 16-byte loads (16 / 26 / 53 taps); needs >= 16 columns of slack in
-            // the source for the loads of the first rows (any real frame)
+            // staged form where it measured faster than the gather form (32 / 12 KITTI frames, rocprofv3): 13 taps 47.7 us
+            // against 58, 49 taps 33.7 against 36; at 25 taps the gather form wins (28.5 against 30.8) and keeps the job;
+            // tiny sources keep the gather form too
             J.h_window = (J.h_taps || force_gather || J.in_w < 64) ? 0
-                         : (ks <= 13 ? 13 : (ks <= 16 ? 16 : (ks <= 26 ? 26 : (ks <= 49 ? 49 : (ks <= 53 ? 53 : 0)))));
-            win_used |= J.h_window == 13 ? 1u : (J.h_window == 16 ? 2u : (J.h_window == 26 ? 4u : (J.h_window == 49 ? 8u : (J.h_window == 53 ? 16u : 0u))));
+                         : (ks <= 13 ? 13 : (ks <= 16 ? 16 : (ks <= 26 ? (force_staged ? 26 : 0) : (ks <= 49 ? 49 : (ks <= 53 ? 53 : 0)))));
+            if (J.h_window) {
+                const int slot = J.h_window == 13 ? 0 : (J.h_window == 16 ? 1 : (J.h_window == 26 ? 2 : (J.h_window == 49 ? 3 : 4)));
+                const double scale = (double)J.in_w / J.out_w;
+                const int span_px = (int)ceil(63.0 * scale) + ks + 2;
+                const int pitch = ((3 * span_px + 16 + 15) / 16) * 16;
+                if (HS_ROWS * pitch > 60 * 1024) {
+                    J.h_window = 0;                      // (cannot happen for <= 53 taps: scale < 9, span < 640 pixels)
+                } else {
+                    win_used |= 1u << slot;
+                    win_pitch[slot] = pitch > win_pitch[slot] ? pitch : win_pitch[slot];
+                }
+            }
             if (J.h_taps) {
                 taps_used |= J.h_taps == 6 ? 4u : 8u;
                 taps_out_w = J.out_w > taps_out_w ? J.out_w : taps_out_w;
             } else {
-                ++n_cols;
                 cols_out_w = J.out_w > cols_out_w ? J.out_w : cols_out_w;
             }
             n_gather += (!J.h_taps && !J.h_window) ? 1 : 0;
@@ -652,22 +708,17 @@ MDX_EXPORT int mdx_resample_lanczos_u8(const mdx_resample_job *jobs, int njobs, 
             max_out_h = J.out_h > max_out_h ? J.out_h : max_out_h;
         }
         const dim3 cg((cols_out_w + 63) / 64, (max_in_h + 4 * HR - 1) / (4 * HR), n);
-        if (n_cols) {
-            // gather-form jobs, and of the window-form jobs the waves on an image's last rows whose windows could leave the
-            // row pitch: when every job is in window form only the row blocks that hold a last row are launched
-            dim3 g = cg;
-            a.y_block0 = 0;
-            if (n_gather == 0) {
-                a.y_block0 = (min_in_h - 1) / (4 * HR);
-                g.y = (max_in_h - 1) / (4 * HR) - a.y_block0 + 1;
-            }
-            hipLaunchKernelGGL(resample_h_kernel, g, dim3(256), 0, st, a);
+        if (n_gather) hipLaunchKernelGGL(resample_h_kernel, cg, dim3(256), 0, st, a);          // gather-form jobs
+        // staged-form jobs: one launch per tap count; LDS = 16 rows x the widest span of 64 columns among the jobs
+        // (span <= 63 * scale + ksize + 1 pixels; + 16 bytes for the alignment of its start, rounded up to 16)
+#define MDX_STAGED_LAUNCH(bit, KTV)                                                                              \
+        if (win_used & bit) {                                                                                    \
+            const int pitch = win_pitch[KTV == 13 ? 0 : (KTV == 16 ? 1 : (KTV == 26 ? 2 : (KTV == 49 ? 3 : 4)))]; \
+            hipLaunchKernelGGL(resample_h_staged_kernel<KTV>, cg, dim3(256), (size_t)HS_ROWS * pitch + 3 * HS_ROWS * 64, st, a, pitch); \
         }
-        if (win_used & 1u) hipLaunchKernelGGL((resample_h_window_kernel<3, 13, 4>), cg, dim3(256), 0, st, a);
-        if (win_used & 2u) hipLaunchKernelGGL((resample_h_window_kernel<3, 16, 4>), cg, dim3(256), 0, st, a);
-        if (win_used & 4u) hipLaunchKernelGGL((resample_h_window_kernel<5, 26, 2>), cg, dim3(256), 0, st, a);
-        if (win_used & 8u) hipLaunchKernelGGL((resample_h_window_kernel<10, 49, 1>), cg, dim3(256), 0, st, a);
-        if (win_used & 16u) hipLaunchKernelGGL((resample_h_window_kernel<10, 53, 1>), cg, dim3(256), 0, st, a);
+        MDX_STAGED_LAUNCH(1u, 13) MDX_STAGED_LAUNCH(2u, 16) MDX_STAGED_LAUNCH(4u, 26) MDX_STAGED_LAUNCH(8u, 49)
+        MDX_STAGED_LAUNCH(16u, 53)
+#undef MDX_STAGED_LAUNCH
         const dim3 tg((taps_out_w + 3) / 4, (max_in_h + HT_ROWS - 1) / HT_ROWS, n);
         if (taps_used & 4u) hipLaunchKernelGGL(resample_h_taps_kernel<6>, tg, dim3(256), 0, st, a);
         if (taps_used & 8u) hipLaunchKernelGGL(resample_h_taps_kernel<8>, tg, dim3(256), 0, st, a);

@@ -239,14 +239,17 @@ __global__ __launch_bounds__(NT) void reprojection_fwd_kernel(const float *__res
 
 // gather form of the SSIM+L1 backward: every pixel q sums the contributions of the (up to 25)
 // padded taps that reflect onto it.  swap = true computes the gradient wrt the TARGET instead.
+// SSIM_ONLY: the backward of SSIM.forward alone (model_loss.py:28-41): the upstream gradient is per channel
+// ([BC,H,W], `B` counts channel planes), no channel mean, no L1 term.
+template <bool SSIM_ONLY>
 __global__ __launch_bounds__(NT) void reprojection_bwd_kernel(const float *__restrict__ pred, const float *__restrict__ target,
                                                               const float *__restrict__ gout, int B, int H, int W,
                                                               float *__restrict__ gres, bool swap)
 {
     const size_t HW = (size_t)H * W;
     const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
-    if (i >= (size_t)B * 3 * HW) return;
-    const size_t bc = i / HW, p = i % HW, b = bc / 3;
+    if (i >= (size_t)B * (SSIM_ONLY ? 1 : 3) * HW) return;
+    const size_t bc = i / HW, p = i % HW, b = SSIM_ONLY ? bc : bc / 3;
     const int qy = (int)(p / W), qx = (int)(p % W);
     const float *xs = (swap ? target : pred) + bc * HW, *ys = (swap ? pred : target) + bc * HW;
     const float *go = gout + b * HW;
@@ -263,15 +266,18 @@ __global__ __launch_bounds__(NT) void reprojection_bwd_kernel(const float *__res
             float x9[9], y9[9];
             load9(xs, H, W, cy, cx, x9);
             load9(ys, H, W, cy, cx, y9);
-            const SsimGrad sg = ssim_grad(pred_stats(x9, y9), target_stats(y9), (0.85f / 3.0f) * go[(size_t)cy * W + cx]);
+            const SsimGrad sg = ssim_grad(pred_stats(x9, y9), target_stats(y9),
+                                          (SSIM_ONLY ? 1.0f : 0.85f / 3.0f) * go[(size_t)cy * W + cx]);
             const float wgt = wy * wx;
             A += wgt * sg.alpha; Bq += wgt * sg.beta; Cq += wgt * sg.gamma;
         }
     }
     float g = (A + 2.0f * xq * Bq + yq * Cq) * (1.0f / 9.0f);
     // L1: d|y-x|/dx = -sign(y-x); wrt y (swap) the roles exchange and the sign is the same expression
-    const float sgn = (yq > xq) ? 1.f : ((yq < xq) ? -1.f : 0.f);
-    g -= 0.05f * sgn * go[p];
+    if (!SSIM_ONLY) {
+        const float sgn = (yq > xq) ? 1.f : ((yq < xq) ? -1.f : 0.f);
+        g -= 0.05f * sgn * go[p];
+    }
     gres[i] = g;
 }
 
@@ -449,11 +455,26 @@ MDX_EXPORT int mdx_reprojection_loss_bwd(const float *pred, const float *target,
     MDX_REQUIRE(B > 0 && H >= 4 && W >= 4, MDX_ERR_BAD_SHAPE);
     const size_t n = (size_t)B * 3 * H * W;
     if (gpred)
-        hipLaunchKernelGGL(reprojection_bwd_kernel, grid1d(n), dim3(NT), 0, (hipStream_t)stream, pred, target, gout,
+        hipLaunchKernelGGL(reprojection_bwd_kernel<false>, grid1d(n), dim3(NT), 0, (hipStream_t)stream, pred, target, gout,
                            B, H, W, gpred, false);
     if (gtarget)
-        hipLaunchKernelGGL(reprojection_bwd_kernel, grid1d(n), dim3(NT), 0, (hipStream_t)stream, pred, target, gout,
+        hipLaunchKernelGGL(reprojection_bwd_kernel<false>, grid1d(n), dim3(NT), 0, (hipStream_t)stream, pred, target, gout,
                            B, H, W, gtarget, true);
+    return check_launch();
+}
+
+MDX_EXPORT int mdx_ssim_bwd(const float *x, const float *y, const float *gout, int BC, int H, int W, float *gx, float *gy,
+                            void *stream)
+{
+    MDX_REQUIRE(x && y && gout && (gx || gy), MDX_ERR_NULL_POINTER);
+    MDX_REQUIRE(BC > 0 && H >= 4 && W >= 4, MDX_ERR_BAD_SHAPE);
+    const size_t n = (size_t)BC * H * W;
+    if (gx)
+        hipLaunchKernelGGL(reprojection_bwd_kernel<true>, grid1d(n), dim3(NT), 0, (hipStream_t)stream, x, y, gout, BC, H, W,
+                           gx, false);
+    if (gy)
+        hipLaunchKernelGGL(reprojection_bwd_kernel<true>, grid1d(n), dim3(NT), 0, (hipStream_t)stream, x, y, gout, BC, H, W,
+                           gy, true);
     return check_launch();
 }
 

@@ -51,7 +51,7 @@ SYMBOLS = {
     "mdx_backproject_fwd": C.c_int, "mdx_backproject_bwd": C.c_int,
     "mdx_project_workspace_bytes": C.c_size_t, "mdx_project_fwd": C.c_int, "mdx_project_bwd": C.c_int,
     "mdx_grid_sample_border_fwd": C.c_int, "mdx_grid_sample_border_bwd": C.c_int,
-    "mdx_reprojection_loss_fwd": C.c_int, "mdx_reprojection_loss_bwd": C.c_int, "mdx_ssim_fwd": C.c_int,
+    "mdx_reprojection_loss_fwd": C.c_int, "mdx_reprojection_loss_bwd": C.c_int, "mdx_ssim_fwd": C.c_int, "mdx_ssim_bwd": C.c_int,
     "mdx_min_automask_fwd": C.c_int,
     "mdx_event_create": C.c_void_p, "mdx_event_destroy": None, "mdx_event_elapsed_us": C.c_int,
     "mdx_photometric_fwd_timed": C.c_int, "mdx_photometric_bwd_timed": C.c_int,

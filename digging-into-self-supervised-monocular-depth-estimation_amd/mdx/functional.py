@@ -552,13 +552,33 @@ def reprojection_loss(pred, target):
     return _ReprojectionLoss.apply(pred, target)
 
 
+class _Ssim(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y):
+        x, y = _f32c(x), _f32c(y)
+        B, Cc, H, W = x.shape
+        out = torch.empty_like(x)
+        check(lib().mdx_ssim_fwd(ptr(x), ptr(y), B * Cc, H, W, ptr(out), stream()), "mdx_ssim_fwd")
+        ctx.save_for_backward(x, y)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, y = ctx.saved_tensors
+        B, Cc, H, W = x.shape
+        gout = _f32c(gout)
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gy = torch.empty_like(x) if ctx.needs_input_grad[1] else None
+        if gx is None and gy is None:
+            return None, None
+        check(lib().mdx_ssim_bwd(ptr(x), ptr(y), ptr(gout), B * Cc, H, W, ptr(gx, optional=True), ptr(gy, optional=True),
+                                 stream()), "mdx_ssim_bwd")
+        return gx, gy
+
+
 def ssim(x, y):
-    """SSIM map (no autograd: use reprojection_loss for training)."""
-    x, y = _f32c(x), _f32c(y)
-    B, Cc, H, W = x.shape
-    out = torch.empty_like(x)
-    check(lib().mdx_ssim_fwd(ptr(x), ptr(y), B * Cc, H, W, ptr(out), stream()), "mdx_ssim_fwd")
-    return out
+    """SSIM map clamp((1 - SSIM) / 2, 0, 1) of model_loss.py:28-41, differentiable in both images."""
+    return _Ssim.apply(x, y)
 
 
 def min_automask(ident, noise, reproj, automask=True, need_combined=False):

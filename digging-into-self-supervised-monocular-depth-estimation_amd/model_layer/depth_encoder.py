@@ -23,22 +23,30 @@ class BatchNorm2d(nn.BatchNorm2d):
     which does read the counter) keeps the stock behaviour."""
 
     fused_min_elements = 0          # per channel (B*H*W): below it act() takes the torch ops (a test / A-B switch)
-    _batch_groups = 1               # see batch_groups()
+    _batch_groups = 1               # default of every instance; batch_groups() sets it on the modules of ONE network
 
-    @classmethod
-    def batch_groups(cls, groups):
-        """Context manager: inside it every BatchNorm2d treats its input batch as `groups` consecutive sub-batches,
-        each with its own batch statistics and its own running-statistics update -- the result of calling the
-        network once per sub-batch, from ONE pass of the convolutions over the whole batch."""
+    @staticmethod
+    def batch_groups(groups, network):
+        """Context manager: inside it every BatchNorm2d OF `network` treats its input batch as `groups` consecutive
+        sub-batches, each with its own batch statistics and its own running-statistics update -- the result of calling the
+        network once per sub-batch, from ONE pass of the convolutions over the whole batch.  Per instance: no other
+        network (and no other thread's forward) is affected."""
         import contextlib
 
         @contextlib.contextmanager
         def scope():
-            prev, cls._batch_groups = cls._batch_groups, int(groups)
+            mods = [m for m in network.modules() if isinstance(m, BatchNorm2d)]
+            prev = [m.__dict__.get("_batch_groups") for m in mods]
+            for m in mods:
+                m._batch_groups = int(groups)
             try:
                 yield
             finally:
-                cls._batch_groups = prev
+                for m, p in zip(mods, prev):
+                    if p is None:
+                        m.__dict__.pop("_batch_groups", None)
+                    else:
+                        m._batch_groups = p
         return scope()
 
     def __init__(self, *args, **kwargs):

@@ -13,7 +13,8 @@ def _require_gpu(t, what):
 
 class SSIM(nn.Module):
     """reference: model_loss/model_loss.py:11-41.  3x3 average-pool SSIM with reflection padding,
-    clamp((1-SSIM)/2, 0, 1).  Differentiable only through ReprojectionLoss (where the reference uses it)."""
+    clamp((1-SSIM)/2, 0, 1).  Differentiable in both images, like the reference's module (closed-form backward,
+    mdx_ssim_bwd)."""
 
     def __init__(self):
         super().__init__()
@@ -22,8 +23,6 @@ class SSIM(nn.Module):
 
     def forward(self, image1, image2):
         _require_gpu(image1, "SSIM")
-        if image1.requires_grad or image2.requires_grad:
-            raise MdxError("SSIM alone is forward-only here; use ReprojectionLoss for a differentiable loss")
         return F.ssim(image1, image2)
 
 

@@ -169,7 +169,7 @@ class compute(object):
             first, second = (frame_id, 0) if frame_id < 0 else (0, frame_id)
             pairs.append(torch.cat([inputs[("color_aug", first, 0)], inputs[("color_aug", second, 0)]], 1))
         n = pairs[0].shape[0]
-        with BatchNorm2d.batch_groups(len(pairs)):
+        with BatchNorm2d.batch_groups(len(pairs), setting.model["pose_encoder"]):
             feats = setting.model["pose_encoder"](torch.cat(pairs, 0))
         axisangle, translation = setting.model["pose_decoder"]([feats])
         for k, frame_id in enumerate(frames):

@@ -261,6 +261,9 @@ int mdx_reprojection_loss_bwd(const float *pred, const float *target, const floa
                               int H, int W, float *gpred, float *gtarget, void *stream);
 /* SSIM.forward alone   model_loss.py:28-41.  x,y [BC,H,W] -> [BC,H,W] */
 int mdx_ssim_fwd(const float *x, const float *y, int BC, int H, int W, float *out, void *stream);
+/* its backward (the reference's SSIM module is differentiable through autograd): gout [BC,H,W] -> gx and / or gy [BC,H,W] */
+int mdx_ssim_bwd(const float *x, const float *y, const float *gout, int BC, int H, int W, float *gx, float *gy,
+                 void *stream);
 
 /* identity+noise, concat, per-pixel min   processor.py:194-204.  ident/noise/reproj [B,S,H,W]
  * -> combined [B,C,H,W] (optional), to_opt [B,H,W], idx [B,H,W] uint8 */

@@ -139,17 +139,39 @@ def main():
         t_inj = timeit(lambda: F.photometric_prologue(tgt, srcs, nsc, noises=noises))
         t_randn = timeit(lambda: torch.randn((nsc, B, S, H, W), device=dev))
         pre = F.photometric_prologue(tgt, srcs, nsc, noises=noises)
-        F.TIMING = {"train": []}
-        t_call = timeit(lambda: F.photometric_train(disps, P, tgt, srcs, invK, pre=pre))
-        torch.cuda.synchronize()
-        tsum = F.timing_summary(F.TIMING)
-        F.TIMING = None
-        with torch.no_grad():
-            F.TIMING = {"eval": []}
-            t_eval = timeit(lambda: F.photometric_train(disps, P, tgt, srcs, invK, pre=pre))
+        # the kernels through the C-ABI directly (as the `train` path below): the Python wrapper's per-call work would let
+        # the queue run dry between launches and inflate event timings
+        td = _lib.make_train_desc(B, H, W, S, [tuple(x.shape[2:]) for x in disps], True, 0.1, 100.0, a.rows)
+        idxs = [torch.empty(B, H, W, dtype=torch.uint8, device=dev) for _ in range(nsc)]
+        sums = torch.empty(nsc, device=dev)
+        gdisps = [torch.empty_like(x) for x in disps]
+        gPs = torch.empty(nsc, S, B, 3, 4, device=dev)
+        nws = lib.mdx_photometric_train_workspace_bytes(C.byref(td))
+        ws = torch.empty(nws // 16 + 1, 2, dtype=torch.float64, device=dev)
+        pd, pP = _lib.ptr_array([x.detach() for x in disps]), _lib.ptr_array([P] * nsc)
+        pi, pg, pb = _lib.ptr_array(idxs, torch.uint8), _lib.ptr_array(gdisps), _lib.ptr_array(pre["bidfi"])
+
+        def train_pre(grads, hook=None):
+            _lib.check(lib.mdx_photometric_train_pre(
+                C.byref(td), pd, _lib.ptr(tgt), C.byref(src), _lib.ptr(invK), pP, _lib.ptr(pre["tstat"]), pb, None, pi,
+                _lib.ptr(sums), pg if grads else None, _lib.ptr(gPs) if grads else None, None, None,
+                _lib.ptr(ws, torch.float64), C.c_size_t(nws), _lib.stream(), C.byref(hook) if hook is not None else None),
+                "train_pre")
+
+        def kernel_us(grads):
+            hooks = [_lib.Timing(lib.mdx_event_create(), lib.mdx_event_create()) for _ in range(a.reps)]
+            for hk in hooks:
+                train_pre(grads, hk)
             torch.cuda.synchronize()
-            esum = F.timing_summary(F.TIMING)
-            F.TIMING = None
+            us = []
+            for hk in hooks:
+                v = C.c_float()
+                _lib.check(lib.mdx_event_elapsed_us(C.c_void_p(hk.start), C.c_void_p(hk.stop), C.byref(v)), "elapsed")
+                us.append(v.value)
+            return sum(us) / len(us)
+        t_call = timeit(lambda: train_pre(True))
+        t_eval = timeit(lambda: train_pre(False))
+        tsum, esum = {"train": (kernel_us(True), a.reps)}, {"eval": (kernel_us(False), a.reps)}
         print("prologue: drawn noise %.1f us, injected noise %.1f us (torch.randn of the %d x [B,S,H,W] maps alone: %.1f us)"
               % (t_drawn, t_inj, nsc, t_randn))
         print("train_pre (%d scales): whole call %.1f us, fused kernel %.1f us; forward-only form: call %.1f us, kernel %.1f us"

@@ -41,14 +41,7 @@ def main():
            "source": ("tools/pmc_bench.sh: rocprofv3 --pmc over `python bench.py` itself (the timed step's own launches and "
                       "tensors), means per launch" if "pmc_bench" in src else
                       "tools/pmc_train.sh (tools/kbench.py --what train), means per launch"), "kernels": {}}
-    # registers / occupancy of the shipped code object (what sets the issue ceiling): from the kernel trace
-    regs = {}
-    for f in glob.glob(os.path.join(src, "trace", "**", "*_kernel_trace.csv"), recursive=True):
-        for r in csv.DictReader(open(f)):
-            name = r["Kernel_Name"].replace("void ", "").split("(")[0]
-            if "VGPR_Count" in r:
-                regs[name] = {"vgprs": int(r["VGPR_Count"]), "accum_vgprs": int(r.get("Accum_VGPR_Count", 0) or 0),
-                              "sgprs": int(r.get("SGPR_Count", 0) or 0), "lds_bytes": int(r.get("LDS_Block_Size", 0) or 0)}
+    regs = {}      # registers / occupancy: tools/kernel_resources.py (the trace's VGPR_Count field is not the ISA's count)
     for k, d in agg.items():
         m = {c: sum(v) / len(v) for c, v in d.items()}
         e = {"counters": m}
@@ -60,6 +53,10 @@ def main():
             e["valu_wave_insts"] = m["SQ_INSTS_VALU"]
             e["valu_issue_us"] = m["SQ_INSTS_VALU"] / SIMDS * 2.0 / (CLK_GHZ * 1e3)        # 2 cycles per wave64 VALU op
             e["valu_issue_us_at_3_waves"] = m["SQ_INSTS_VALU"] / SIMDS / RATE_3WAVES / (CLK_GHZ * 1e3)
+        if "SQ_ACTIVE_INST_VALU" in m:
+            # SQ_ACTIVE_INST_VALU counts, in units of 4 cycles, the time waves spend with a VALU instruction executing: summed
+            # over the waves of a SIMD it is the time that SIMD's vector ALU is occupied (a wave64 instruction holds it 4 cycles)
+            e["valu_busy_us"] = m["SQ_ACTIVE_INST_VALU"] * 4.0 / SIMDS / (CLK_GHZ * 1e3)
         if "SQ_WAVE_CYCLES" in m:
             for key, c in (("wait_any_frac", "SQ_WAIT_ANY"), ("wait_inst_frac", "SQ_WAIT_INST_ANY"), ("active_frac", "SQ_ACTIVE_INST_ANY")):
                 if c in m:
