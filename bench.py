@@ -345,7 +345,7 @@ def trainer_loop(args, frame_ids, steps, warmup, workers, raw):
             "raw_frames": raw, "what": "model_train.trainer: DataLoader (" + ("decoded 1242x375 frames, Lanczos pyramid / jitter / ToTensor on the GPU, " if raw else "prepared uint8 entries, ") + "pinned, side-stream upload) -> train_step -> control.metric every step", "abs_rel_monitor": vals.get("abs_rel")}
 
 
-def trainer_loop_child(feed, port_offset=1):
+def trainer_loop_child(feed, port=None):
     """`python bench.py --trainer-loop-child raw|prepared <same shape arguments>` in a fresh process; its one JSON line.
     In a multi-rank job every rank starts its own child (never a re-exec) and the children form a job of their own on
     the next rendezvous port: the loop is measured with the gradient exchange in it."""
@@ -354,7 +354,7 @@ def trainer_loop_child(feed, port_offset=1):
     cmd = [sys.executable, os.path.abspath(__file__), "--trainer-loop-child", feed] + keep
     env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        env["MASTER_PORT"] = str(int(os.environ["MASTER_PORT"]) + port_offset)
+        env["MASTER_PORT"] = str(port)             # a free port rank 0 picked and broadcast to the job
     else:
         for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
             env.pop(k, None)
@@ -562,10 +562,14 @@ def main():
         # loader workers and allocator state and measured 5 % low): fed with decoded 1242x375 frames (the data path of
         # a real run: pyramid / jitter / ToTensor are extra GPU work the resident figure does not contain) and with
         # ready entries (the loop alone)
+        ports = torch.tensor([free_port(), free_port()] if rank == 0 else [0, 0], dtype=torch.int64,
+                             device=device if (distributed and backend == "nccl") else "cpu")
+        if distributed:
+            torch.distributed.broadcast(ports, 0)      # the children of every rank meet on rank 0's choice
         for k, (key, feed) in enumerate((("trainer_loop", "raw"), ("trainer_loop_prepared_frames", "prepared"))):
             if key != "trainer_loop" and args.one_loop:
                 continue
-            res = trainer_loop_child(feed, port_offset=k + 1)
+            res = trainer_loop_child(feed, port=int(ports[k]))
             failed = failed or "error" in res
             if rank == 0:
                 line[key] = res
@@ -583,6 +587,9 @@ def main():
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))
     if distributed:
+        flag = torch.tensor([1.0 if failed else 0.0], device=device if backend == "nccl" else "cpu")
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)     # every rank leaves with the same code
+        failed = bool(flag[0] > 0)
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
     if failed:

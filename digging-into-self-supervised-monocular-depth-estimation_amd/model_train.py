@@ -111,7 +111,17 @@ class graphed_step(object):
         # (and RCCL's watchdog thread polls events) while this thread captures; in the default "global" mode such a
         # call from ANY thread invalidates the capture
         with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="thread_local"):
-            self.outputs = tr._eager_step(dict(self.static))
+            outputs = tr._eager_step(dict(self.static))
+        # the graph's output tensors, without the autograd graph behind them: a loss that kept its grad_fn would keep the
+        # capture pass's gradient-accumulation nodes (created on the capture stream) alive into later eager steps
+        def _plain(v):
+            if torch.is_tensor(v):
+                return v.detach()
+            if isinstance(v, (list, tuple)):
+                return type(v)(_plain(x) for x in v)
+            return v
+        self.outputs = {k: _plain(v) for k, v in outputs.items()}
+        del outputs
         self.bn_incr = [m._pending_batches - b for m, b in zip(self.bns, before)]
         for m, b in zip(self.bns, before):         # the capture pass ran no kernel: it was not a step
             m._pending_batches = b
@@ -137,6 +147,7 @@ class trainer(object):
         world = int(os.environ.get("WORLD_SIZE", "1"))
         local = int(os.environ.get("LOCAL_RANK", "0"))
         if torch.cuda.is_available():
+            local = local % torch.cuda.device_count()     # a rehearsal may run several ranks on one GPU (gloo backend)
             self.device = "cuda:%d" % local
             torch.cuda.set_device(local)
         else:

@@ -220,7 +220,12 @@ def test_trainer_graph_replay_matches_eager(G):
     _same_trajectory(graph, eager)
     step = [float(v["step"]) for v in tr.setting.optim["optimizer"].state.values()]
     assert step and all(v == 6.0 for v in step), sorted(set(step))
-    o1 = float(tr._eager_step(dict(tr._graphed.static))["loss"].detach())
+    # an eager step from the same state, on the stream the graph was captured on (its gradient-accumulation nodes live
+    # there; on the default stream torch warns about the mismatch -- tools/diag_accgrad_warning.py: the trainer's own
+    # flow, warm-up + capture + replays, raises no such warning)
+    with torch.cuda.stream(tr._graphed.stream):
+        o1 = float(tr._eager_step(dict(tr._graphed.static))["loss"].detach())
+    torch.cuda.current_stream().wait_stream(tr._graphed.stream)
     o2 = float(tr._graphed(dict(tr._graphed.static))["loss"].detach())
     assert np.isfinite(o1) and np.isfinite(o2) and abs(o1 - o2) < 0.05 * abs(o1)
 
