@@ -1266,6 +1266,13 @@ static void choose_levels(const mdx_train_desc *d, TrainPlan &p)
         r[0] = H >= 160 ? 40 : (H >= 64 ? 24 : 16);
         r[1] = r[0] / 2;
         r[2] = r[1] / 2 > 4 ? r[1] / 2 : 4;
+        if (H >= 160 && H < 256) {
+            // re-swept in round 3 for the BASELINE height (tools/sweep_schedule.sh, timing inside the real step): with the
+            // gradient phase skipped in auto-masked regions a halo step costs relatively more, and fewer, taller chunks win --
+            // 3 x 40 + 2 x 24 + 2 x 12 rows (7 chunks, 220 steps per column) 210.5 us against 223.7 us for round 2's
+            // 2 x 40 + 2 x 20 + 8 x 10 (12 chunks, 240 steps); 3 x 40 + 3 x 24 (6 chunks) is unbalanced again (224.6 us)
+            r[1] = 24; r[2] = 12; f1 = 0.63; f2 = 0.25;
+        }
 #ifdef MDX_DEV_SWITCHES      // sweeps of the builder only (MDX_BUILD_DEFINES=-DMDX_DEV_SWITCHES): the shipped library never reads the environment
         if (const char *e = getenv("MDX_TRAIN_SCHEDULE")) {
             int a0, a1, a2;
