@@ -40,7 +40,7 @@ constexpr int SW = 60;   // output columns per wave (64 lanes - 2 x 2 halo lanes
 #endif
 #ifndef MDX_TRAIN_WAVE_UNIFORM
 #define MDX_TRAIN_WAVE_UNIFORM 0  // per-wave (not per-lane) choice of the u/(W-1), v/(H-1) division form and of the corner border
-                                  // handling: ~70 fewer VALU instructions per step on paper, +1 % time measured (tools/ab_bench2.sh)
+                                  // handling: ~70 fewer VALU instructions per step on paper, +1 % time measured (tools/ab_bench_repeat.sh)
 #endif
 #ifndef MDX_EVAL_WAVES
 #define MDX_EVAL_WAVES 5          // waves per SIMD of the forward-only form for S <= 2 (96 VGPRs)

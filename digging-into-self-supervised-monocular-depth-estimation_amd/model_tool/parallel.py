@@ -29,14 +29,8 @@ step uses ONE bucket, issued when backward ends (`setting` picks bucket_mb accor
 xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce of the 107 MB (ResNet-18 depth + pose, fp32) is
 link-bound at ~0.5-1 ms against a >=13 ms step.  `comm_dtype=torch.bfloat16` halves the bytes (gradients are rounded
 once before the sum; off by default)."""
-import os
-
 import torch
 import torch.distributed as dist
-
-# measurement switches (tools/r3_step2.sh): leave the collective out / issue it synchronously
-_NO_COMM = os.environ.get("MDX_SYNC_NO_COMM") == "1"
-_SYNC_COMM = os.environ.get("MDX_SYNC_BLOCKING") == "1"
 
 
 def _align(n, a=64):
@@ -44,6 +38,8 @@ def _align(n, a=64):
 
 
 class grad_sync(object):
+    no_comm = False       # measurement aid (profiles/r03_dp_step.txt "nocomm" rows): everything but the collective itself
+
     def __init__(self, parameters, bucket_mb=32, group=None, comm_dtype=None):
         self.group = group
         self.world = dist.get_world_size(group)
@@ -119,10 +115,10 @@ class grad_sync(object):
             cbuf = self.comm[a:b]
             cbuf.copy_(buf)
             buf = cbuf
-        if _NO_COMM:
+        if self.no_comm:
             return
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
-        self._works.append((k, dist.all_reduce(buf, op=op, group=self.group, async_op=not _SYNC_COMM)))
+        self._works.append((k, dist.all_reduce(buf, op=op, group=self.group, async_op=True)))
 
     def finish(self):
         """After backward: every bucket exchanged and visible to the current stream (no host synchronisation on GPU)."""
@@ -130,8 +126,7 @@ class grad_sync(object):
             self._issue(self._next)
             self._next += 1
         for k, w in self._works:
-            if w is not None:
-                w.wait()                   # nccl: the current stream waits for the communicator's stream; gloo: blocks
+            w.wait()                   # nccl: the current stream waits for the communicator's stream; gloo: blocks
             if self.comm is not None:
                 a, b, _ = self.buckets[k]
                 self.flat[a:b].copy_(self.comm[a:b])

@@ -1,7 +1,7 @@
 #!/bin/bash
 set -o pipefail
 ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
-OUT="$ROOT/gpurun_out/r3img"; mkdir -p "$OUT"; cd "$ROOT"
+OUT="$ROOT/gpurun_out/imgproc_round3"; mkdir -p "$OUT"; cd "$ROOT"
 timeout -k 10 600 python -m pytest tests/test_gpu_imgproc.py -x -q > "$OUT/pytest_img.log" 2>&1; echo "pytest rc=$?"; tail -4 "$OUT/pytest_img.log"
 bash tools/trace_imgbench.sh s0 --n 32 --out 192x640
 bash tools/trace_imgbench.sh s1 --n 12 --out 96x320
