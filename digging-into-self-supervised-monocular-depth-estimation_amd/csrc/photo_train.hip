@@ -42,6 +42,12 @@ constexpr int SW = 60;   // output columns per wave (64 lanes - 2 x 2 halo lanes
 #define MDX_TRAIN_WAVE_UNIFORM 0  // per-wave (not per-lane) choice of the u/(W-1), v/(H-1) division form and of the corner border
                                   // handling: ~70 fewer VALU instructions per step on paper, +1 % time measured (tools/ab_bench_repeat.sh)
 #endif
+#ifndef MDX_TRAIN_WU_NORM
+#define MDX_TRAIN_WU_NORM MDX_TRAIN_WAVE_UNIFORM
+#endif
+#ifndef MDX_TRAIN_WU_CORNER
+#define MDX_TRAIN_WU_CORNER MDX_TRAIN_WAVE_UNIFORM
+#endif
 #ifndef MDX_EVAL_WAVES
 #define MDX_EVAL_WAVES 5          // waves per SIMD of the forward-only form for S <= 2 (96 VGPRs)
 #endif
@@ -309,7 +315,7 @@ MDX_DEV Proj project_point_train(const float *__restrict__ P, float X0, float X1
     float nx, ny;
     const float au = fabsf(p.u), av = fabsf(p.v);
     const bool fast_ok = nd.w.fast && nd.h.fast && au > 1e-30f && au < 3.0e38f && av > 1e-30f && av < 3.0e38f;
-    if (MDX_TRAIN_WAVE_UNIFORM && __builtin_amdgcn_ballot_w64(!fast_ok) == 0) {
+    if (MDX_TRAIN_WU_NORM && __builtin_amdgcn_ballot_w64(!fast_ok) == 0) {
         nx = div_by_const(p.u, nd.w.b, nd.w.r);
         ny = div_by_const(p.v, nd.h.b, nd.h.r);
     } else {
@@ -325,7 +331,7 @@ MDX_DEV Proj project_point_train(const float *__restrict__ P, float X0, float X1
 // needs the pair shifted / the lower pair zeroed (four selects per channel); only waves that hold such a tap pay for them.
 MDX_DEV Corners load_corners_train(const float *__restrict__ img, int H, int W, const Tap &t, bool border_wave)
 {
-    if (!MDX_TRAIN_WAVE_UNIFORM || border_wave) return load_corners(img, H, W, t);
+    if (!MDX_TRAIN_WU_CORNER || border_wave) return load_corners(img, H, W, t);
     const unsigned o0 = (unsigned)(t.y0 * W + t.x0) * 4u, o1 = o0 + (unsigned)W * 4u;
     const char *base = reinterpret_cast<const char *>(img);
     const float2_a4 top = *reinterpret_cast<const float2_a4 *>(base + o0);
