@@ -68,6 +68,30 @@ def test_null_pointers_and_workspace_are_reported_not_crashed():
         _lib.check(-4, "unit test")
 
 
+def test_round3_entry_points_report_bad_arguments():
+    """mdx_photometric_prologue / mdx_photometric_train_pre / mdx_ssim_bwd / mdx_to_tensor_u8: argument errors come back
+    as status codes (host-side checks only: nothing is launched, no GPU needed)."""
+    lib = _lib.lib()
+    td = _lib.make_train_desc(1, 32, 64, 2, [(32, 64), (16, 32)], True, 0.1, 100.0)
+    assert lib.mdx_photometric_train_workspace_bytes(C.byref(td)) > 0
+    assert lib.mdx_photometric_prologue(None, None, None, None, None, 0, None, None, None, None) == -2
+    assert lib.mdx_photometric_prologue(C.byref(td), None, None, None, None, 0, None, None, None, None) == -2
+    bad = _lib.TrainDesc()
+    C.memmove(C.byref(bad), C.byref(td), C.sizeof(td))
+    bad.nscales = 9
+    fake = C.c_void_p(4096)          # a non-null, 16-byte aligned address that is never dereferenced on these paths
+    assert lib.mdx_photometric_prologue(C.byref(bad), fake, None, None, None, 0, None, fake, None, None) == -1
+    # auto-mask on: sources / outputs per scale / a noise source are required
+    assert lib.mdx_photometric_prologue(C.byref(td), fake, None, None, None, 0, None, fake, None, None) == -2
+    assert lib.mdx_photometric_train_pre(C.byref(td), None, None, None, None, None, None, None, None, None, None, None,
+                                         None, None, None, None, C.c_size_t(0), None, None) == -2
+    assert lib.mdx_ssim_bwd(None, None, None, 3, 8, 8, None, None, None) == -2
+    assert lib.mdx_ssim_bwd(fake, fake, fake, 3, 2, 8, fake, None, None) == -1
+    assert lib.mdx_to_tensor_u8(None, None, C.c_size_t(16), None) == -2
+    assert lib.mdx_to_tensor_u8(fake, fake, C.c_size_t(0), None) == -1
+    assert lib.mdx_to_tensor_u8(fake, C.c_void_p(4100), C.c_size_t(16), None) == -6      # destination not 16-byte aligned
+
+
 def test_cpu_tensors_are_refused_loudly():
     import torch
     from mdx import functional as F
