@@ -18,7 +18,8 @@ def options(argv=None):
     p.add_argument("--prepetch", type=int, default=2)
     p.add_argument("--num_workers", type=int, default=12,
                    help="DataLoader workers per process (reference default, model_option.py:32-34).  With --gpu_image_prep 12 "
-                        "workers deliver ~700-800 samples/s, 16 ~1100 (tools/loader_cost.py --workers N)")
+                        "workers deliver ~700-860 samples/s, 16 ~1100 (tools/loader_cost.py --workers N); -1 = sized for "
+                        "this rank (12, or 16 with --amp bf16 whose step consumes ~900 samples/s, capped by the host share)")
     p.add_argument("--learning_rate", type=float, default=1e-4)
     p.add_argument("--scheduler_step", type=int, default=15)
     p.add_argument("--disp_smoothness", type=float, default=1e-3)
