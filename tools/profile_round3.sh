@@ -10,6 +10,7 @@ OUT="$ROOT/gpurun_out/profile_round3"
 if [ "$1" = "--collect" ]; then
     tag="${2:-r03}"
     cd "$ROOT" || exit 1
+    cp "$OUT/bench_kernel_pmc.json" "profiles/${tag}_bench_kernel_pmc.json"     # what bench.py quotes (tied to the library build by its hash)
     cp "$OUT/bench_full.json" "profiles/${tag}_bench_full.json"
     cp "$OUT/bench_bf16_dist_graph.json" "profiles/${tag}_bench_bf16_dist_graph.json"
     python tools/summarize_rocprof.py "$OUT/bench_stats" "profiles/${tag}_bench_kernel_stats.txt" \
