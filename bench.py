@@ -200,18 +200,25 @@ def roofline_blocks(args, opt, frame_ids, tsum):
     dom = max(k, key=lambda n: k[n]["ms"] * k[n]["launches"])
     # Counters of the committed rocprofv3 --pmc passes over THIS command's own launches (tools/pmc_bench.sh profiles
     # `python bench.py` with --kernel-include-regex on the photometric kernels: same tensors as the timed steps).  They
-    # describe one build of the library: tied to it by the hash of libmdx_hip.so and to the workload by its shape;
-    # anything else reports null rather than a stale number.
+    # describe one build of the library: tied to it by the hash of libmdx_hip.so, or -- a rebuild elsewhere embeds other
+    # paths -- by the hash of its sources and flags, and to the workload by its shape; anything else reports null rather
+    # than a stale number.
     traffic = issue = None
     try:
         import hashlib
         pmc = json.load(open(PMC_FILE))
         from mdx import LIB_PATH
         so = hashlib.sha256(open(LIB_PATH, "rb").read()).hexdigest()[:16]
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("_mdx_build", os.path.join(os.path.dirname(LIB_PATH), "build.py"))
+        _build = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(_build)
+        same_build = pmc.get("lib_sha16") == so or (pmc.get("source_sha16") == _build.source_sha16()
+                                                    and "MDX_LIB" not in os.environ)
         ent = next((v for kk, v in pmc["kernels"].items() if kk.startswith(k[dom]["name"].split("<")[0])
                     and ("<%d" % nS) in kk), None)
         same_shape = pmc.get("shape") == [args.batch, opt.height, opt.width, nS, nsc]
-        if ent and same_shape and pmc.get("lib_sha16") == so:
+        if ent and same_shape and same_build:
             traffic = ent.get("traffic_bytes")
             issue = {kk: ent[kk] for kk in ("valu_wave_insts", "valu_issue_us", "valu_busy_us", "wait_any_frac",
                                             "wait_inst_frac", "active_frac", "kernel_us_profiled") if kk in ent}

@@ -25,6 +25,18 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 
 
+def source_sha16():
+    """Identity of a library build that does not depend on where it was compiled: the sources, headers and flags.  The
+    committed counter summaries (profiles/*_kernel_pmc.json) are tied to it; bench.py quotes them only for this build."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(SOURCES) + sorted(HEADERS):
+        h.update(f.encode())
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    h.update(" ".join(FLAGS + FLAGS_EXTRA_ENV + [k + ":" + " ".join(v) for k, v in sorted(EXTRA_FLAGS.items())]).encode())
+    return h.hexdigest()[:16]
+
+
 def _stale():
     if not os.path.exists(LIB):
         return True

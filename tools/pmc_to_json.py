@@ -37,7 +37,9 @@ def main():
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"].replace("void ", "").split("(")[0]
             dur[name].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-    out = {"lib_sha16": hashlib.sha256(open(so, "rb").read()).hexdigest()[:16], "shape": shape,
+    sys.path.insert(0, os.path.dirname(so))
+    import build as B
+    out = {"lib_sha16": hashlib.sha256(open(so, "rb").read()).hexdigest()[:16], "source_sha16": B.source_sha16(), "shape": shape,
            "source": ("tools/pmc_bench.sh: rocprofv3 --pmc over `python bench.py` itself (the timed step's own launches and "
                       "tensors), means per launch" if "pmc_bench" in src else
                       "tools/pmc_train.sh (tools/kbench.py --what train), means per launch"), "kernels": {}}
