@@ -15,7 +15,9 @@
 // Jobs travel BY VALUE in the kernel arguments (<= MDX_IMG_JOBS per launch): no device-side job table to keep alive,
 // nothing to copy, capturable.  Layouts: source = interleaved RGB rows as Pillow / the JPEG decoder hand them over
 // ([h][w][3] uint8, row stride in bytes); everything downstream is planar ([3][h][w]), the step's layout.
+#include <algorithm>
 #include <cmath>
+#include <vector>
 #include <cstdlib>
 #include <cstring>
 #include "mdx_common.hpp"
@@ -24,23 +26,61 @@ namespace mdx {
 
 constexpr int RS_BITS = 32 - 8 - 2;          // Resample.c PRECISION_BITS
 
-struct ResampleJob : mdx_resample_job {
-    int vec4;                 // the vertical pass may use dword accesses (alignment and row length checked on the host)
-    int h_taps;               // horizontal pass: 0 = lanes along the columns, C > 0 = resample_h_taps_kernel<C>
-    int h_window;             // lanes along the columns: 0 = one gather per tap and row, KT > 0 = staged through LDS,
-                              // KT taps evaluated (13, 16, 26, 49, 53)
+// What a launch carries (kernel arguments, by value): the distinct plans of its jobs and the jobs themselves, packed --
+// a batch of 12 samples (36 frames at scale 0 + the target's three smaller scales per sample = 72 jobs) is ONE
+// horizontal and ONE vertical launch.  (Round 2 passed 32 caller-layout jobs of 108 bytes per launch: three launches of
+// each pass per batch, each with its own tail.)
+constexpr int IMG_PLANS = 16;                // distinct (size -> size) plans per launch and axis
+constexpr int IMG_JOBS = MDX_IMG_JOBS;       // jobs per launch (72)
+struct PlanX {
+    const int *bounds, *kk;                  // [out_w][2], [ksize][out_w]
+    int in_w, out_w, ksize;
+    uint8_t lg_cols;                         // rows form: log2(output columns per block); HW_GATHER = gather form
+    uint8_t pad;
+    uint16_t pitch;                          // rows form: LDS row pitch in bytes (4 x an odd number)
 };
-struct ResampleJobs {
-    ResampleJob j[MDX_IMG_JOBS];
+struct PlanY {
+    const int *bounds, *kk;                  // [out_h][2], [ksize][out_h]
+    int in_h, out_h, ksize, pad;
 };
+struct PackedJob {
+    const uint8_t *src;
+    uint8_t *inter, *dst_u8;
+    float *dst_f32;
+    int in_stride;
+    uint8_t px, py, flags, pad;              // plan indices; flags: JOB_FLIP | JOB_VEC4 | JOB_VEC8
+};
+struct ResampleLaunch {
+    PlanX x[IMG_PLANS];
+    PlanY y[IMG_PLANS];
+    PackedJob j[IMG_JOBS];
+};
+static_assert(sizeof(PlanX) == 32 && sizeof(PlanY) == 32 && sizeof(PackedJob) == 40, "packed launch layout");
+static_assert(sizeof(ResampleLaunch) <= 4096, "kernel arguments are limited to 4 KB");
+constexpr int JOB_FLIP = 1, JOB_VEC4 = 2, JOB_VEC8 = 4;
+constexpr int HW_GATHER = 255;
 struct JitterJobs {
-    mdx_jitter_job j[MDX_IMG_JOBS];
+    mdx_jitter_job j[MDX_JITTER_JOBS];
 };
+static_assert(sizeof(JitterJobs) <= 4096, "kernel arguments are limited to 4 KB");
 
 static __device__ __forceinline__ uint8_t clip8(int v)
 {
     v >>= RS_BITS;
     return (uint8_t)min(max(v, 0), 255);
+}
+
+// ToTensor's float32(byte) / 255 without the division sequence: q0 = b * rc, r = fma(-255, q0, b), q = fma(r, rc, q0)
+// with rc = fl(1/255) is the correctly rounded quotient for every byte (all 256 checked in exact rational arithmetic,
+// tests/test_imgproc_cpu.py; on the GPU the bit-exact tests of tests/test_gpu_imgproc.py go through it) -- 3 instructions
+// instead of ~12 per value, in kernels that are bound by the vector ALU.
+static __device__ __forceinline__ float unit_from_byte(unsigned b)
+{
+    const float rc = __builtin_bit_cast(float, 0x3b808081u);       // fl(1 / 255)
+    const float fb = (float)b;
+    const float q0 = fb * rc;
+    const float r = __builtin_fmaf(-255.0f, q0, fb);
+    return __builtin_fmaf(r, rc, q0);
 }
 
 // One byte per lane -> dwords: lane 4q gathers the bytes of lanes 4q..4q+3 (DPP row shifts; groups of four never
@@ -67,31 +107,33 @@ static __device__ __forceinline__ unsigned load32_unaligned(const uint8_t *p)
     return v;
 }
 
-// Horizontal pass: interleaved RGB [in_h][in_w][3] -> planar uint8 inter [3][in_h][out_w].
-// A wave owns 64 consecutive output columns and HR rows (weights, bounds and address arithmetic are shared by the
-// rows; HR x 2 independent loads are in flight); a pixel's three bytes arrive as ONE dword: bytes [3px, 3px+3], or for
-// the last pixel of a row [3px-1, 3px+2] shifted down (never a byte past the row).
+// ---- horizontal pass, GATHER form (the general fallback: any filter width, any size) ----
+// interleaved RGB [in_h][in_w][3] -> planar uint8 inter [3][in_h][out_w].  A wave owns 64 consecutive output columns and
+// HR rows (weights, bounds and address arithmetic are shared by the rows; HR x 2 independent loads are in flight); a
+// pixel's three bytes arrive as ONE dword: bytes [3px, 3px+3], or for the last pixel of a row [3px-1, 3px+2] shifted down
+// (never a byte past the row).  Every tap is a gather at a stride of 3 * in_w / out_w bytes: the address path bounds it
+// (~18 CU-cycles per load instruction, profiles/r02_imgproc_kernel_pmc.txt).  Rounds 2 and 3 built three more forms with
+// lanes along the columns (16-byte window loads; spans staged in LDS and read back as bytes -- ~3 bank passes per read;
+// one wave per column with the taps along the lanes for 65..128-tap filters): each within 20 % of this one.  The ROWS
+// form below replaced them all; this one serves what does not fit its LDS tile.
 constexpr int HR = 4;
-// EDGE: some lane of the wave taps the last pixel of a row (only the last columns do) -- the general form with the
-// shifted load; otherwise every tap is the plain dword at 3*px.  Row bases are wave-uniform (scalar registers), the
-// per-lane part of an address is one 32-bit offset.
 template <bool FLIP, bool EDGE>
-static __device__ __forceinline__ void resample_h_body(const ResampleJob &J, int xo, int y0, bool ok, int lane)
+static __device__ __forceinline__ void resample_h_body(const PackedJob &J, const PlanX &X, int in_h, int xo, int y0, bool ok, int lane)
 {
-    const int xmin = J.xbounds[2 * xo], n = J.xbounds[2 * xo + 1];
-    const int *k = J.xkk + xo;                     // [ksize][out_w]: a wave reads 256 consecutive bytes per tap
+    const int xmin = X.bounds[2 * xo], n = X.bounds[2 * xo + 1];
+    const int *k = X.kk + xo;                      // [ksize][out_w]: a wave reads 256 consecutive bytes per tap
     const uint8_t *row[HR];
     int s[HR][3];
 #pragma unroll
     for (int r = 0; r < HR; ++r) {
-        row[r] = J.src + (size_t)min(y0 + r, J.in_h - 1) * J.in_stride;      // y0 is wave-uniform
+        row[r] = J.src + (size_t)min(y0 + r, in_h - 1) * J.in_stride;        // y0 is wave-uniform
         s[r][0] = s[r][1] = s[r][2] = 1 << (RS_BITS - 1);
     }
-    const int last = J.in_w - 1;
+    const int last = X.in_w - 1;
     unsigned off = 3u * (unsigned)(FLIP ? last - xmin : xmin);
 #pragma unroll 2
     for (int t = 0; t < n; ++t) {
-        const int c = k[(size_t)t * J.out_w];
+        const int c = k[(size_t)t * X.out_w];
         unsigned o = off, sh = 0;
         if (EDGE) {
             const bool edge = off == 3u * (unsigned)last;
@@ -102,293 +144,339 @@ static __device__ __forceinline__ void resample_h_body(const ResampleJob &J, int
         for (int r = 0; r < HR; ++r) {
             unsigned v = load32_unaligned(row[r] + o);
             if (EDGE) v >>= sh;
-            s[r][0] += __mul24((int)(v & 255u), c);             // |weight| < 2^22: v_mad_i32_i24, full rate
+            s[r][0] += __mul24((int)(v & 255u), c);             // |weight| < 2^22: v_mad_i32_i24
             s[r][1] += __mul24((int)((v >> 8) & 255u), c);
             s[r][2] += __mul24((int)((v >> 16) & 255u), c);
         }
         off = FLIP ? off - 3u : off + 3u;
     }
-    const size_t plane = (size_t)J.in_h * J.out_w;
+    const size_t plane = (size_t)in_h * X.out_w;
+    const bool vec4 = (J.flags & JOB_VEC4) != 0;
 #pragma unroll
     for (int r = 0; r < HR; ++r) {
-        const bool row_ok = ok && y0 + r < J.in_h;                     // wave-uniform apart from the column tail
-        const size_t o = (size_t)min(y0 + r, J.in_h - 1) * J.out_w + xo;
-        store_bytes_packed(J.inter + o, clip8(s[r][0]), J.vec4 != 0, row_ok, lane);
-        store_bytes_packed(J.inter + plane + o, clip8(s[r][1]), J.vec4 != 0, row_ok, lane);
-        store_bytes_packed(J.inter + 2 * plane + o, clip8(s[r][2]), J.vec4 != 0, row_ok, lane);
+        const bool row_ok = ok && y0 + r < in_h;                       // wave-uniform apart from the column tail
+        const size_t o = (size_t)min(y0 + r, in_h - 1) * X.out_w + xo;
+        store_bytes_packed(J.inter + o, clip8(s[r][0]), vec4, row_ok, lane);
+        store_bytes_packed(J.inter + plane + o, clip8(s[r][1]), vec4, row_ok, lane);
+        store_bytes_packed(J.inter + 2 * plane + o, clip8(s[r][2]), vec4, row_ok, lane);
     }
 }
 
-// Taps come straight from global memory (L1 / L2 serve the overlap of neighbouring columns and tiles).  An LDS-staged
-// form (row segments copied with 16-byte loads, taps as unaligned ds_read_b32) was measured at 166 us against 60 us for
-// this one on 32 KITTI frames: lanes 6 bytes apart reading unaligned dwords serialise on the LDS banks.
-__global__ __launch_bounds__(256) void resample_h_kernel(ResampleJobs jobs)
+__global__ __launch_bounds__(256) void resample_h_kernel(ResampleLaunch L)
 {
-    const ResampleJob &J = jobs.j[blockIdx.z];
-    if (J.h_taps) return;                                            // this job runs in resample_h_taps_kernel
+    const PackedJob &J = L.j[blockIdx.z];
+    const PlanX &X = L.x[J.px];
+    if (X.lg_cols != HW_GATHER) return;                              // this job runs in resample_h_rows_kernel
+    const int in_h = L.y[J.py].in_h;
     const int lane = threadIdx.x & 63;
     const int xo0 = blockIdx.x * 64;
     // the wave index as a scalar: taken from threadIdx.x alone the compiler treats the row addresses as lane-varying
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int y0 = (blockIdx.y * 4 + wave) * HR;
-    if (xo0 >= J.out_w || y0 >= J.in_h) return;                      // wave-uniform: the packed stores need whole waves
-    const bool ok = xo0 + lane < J.out_w;
-    const int xo = min(xo0 + lane, J.out_w - 1);
+    if (xo0 >= X.out_w || y0 >= in_h) return;                        // wave-uniform: the packed stores need whole waves
+    const bool ok = xo0 + lane < X.out_w;
+    const int xo = min(xo0 + lane, X.out_w - 1);
     // does any lane tap the last source pixel?  (bounds are monotonic: the last column reaches furthest)
-    const int xl = min(xo0 + 63, J.out_w - 1);
-    const bool edge = J.flip ? J.xbounds[2 * xo0] == 0 : J.xbounds[2 * xl] + J.xbounds[2 * xl + 1] == J.in_w;
-    if (J.h_window) return;                                          // this job runs in resample_h_staged_kernel
-    if (J.flip) {
-        if (edge) resample_h_body<true, true>(J, xo, y0, ok, lane);
-        else resample_h_body<true, false>(J, xo, y0, ok, lane);
+    const int xl = min(xo0 + 63, X.out_w - 1);
+    const bool flip = (J.flags & JOB_FLIP) != 0;
+    const bool edge = flip ? X.bounds[2 * xo0] == 0 : X.bounds[2 * xl] + X.bounds[2 * xl + 1] == X.in_w;
+    if (flip) {
+        if (edge) resample_h_body<true, true>(J, X, in_h, xo, y0, ok, lane);
+        else resample_h_body<true, false>(J, X, in_h, xo, y0, ok, lane);
     } else {
-        if (edge) resample_h_body<false, true>(J, xo, y0, ok, lane);
-        else resample_h_body<false, false>(J, xo, y0, ok, lane);
+        if (edge) resample_h_body<false, true>(J, X, in_h, xo, y0, ok, lane);
+        else resample_h_body<false, false>(J, X, in_h, xo, y0, ok, lane);
     }
 }
 
-// STAGED form of the horizontal pass (round 3).  The gather form above issues one 4-byte load per tap and row -- 13 load
-// instructions per output for the 640-column scale -- and the address path, 64 lanes each fetching its own unaligned
-// dword at a ~6-byte stride, is what bounds it (~18 CU-cycles per instruction, profiles/r02_imgproc_kernel_pmc.txt; a form
-// that fetched each lane's 39-byte window with three unaligned 16-byte loads measured the same 57 us: the path is paced by
-// the lanes' scattered addresses, not by the instruction count).  Here a block of 64 output columns x 16 rows first copies
-// the source bytes its columns touch -- ONE contiguous span per row, ~420 bytes for the 640-column scale -- into LDS with
-// coalesced 16-byte loads (each source byte crosses the address path once), then every lane reads its taps from LDS as
-// BYTES (ds_read_u8 with the tap's offset as the instruction's immediate: no address arithmetic, no extraction, no
-// alignment issue -- the first LDS version of round 2 read unaligned dwords and serialised on the banks) and multiplies.
-// A span that runs past the image's last byte is completed with zeros (those taps' weights are zero): nothing is read
-// beyond the image's rows.
-// Flipped images stage the mirrored span and take the weights in reverse.  KT = taps evaluated (>= the filter's ksize).
-// Measured (32 frames 1242x375 -> 640 columns): 47.7 us against 58 us for the gather form.  What bounds it now is the LDS:
-// 64 lanes 6 bytes apart touch ~93 different dwords per read instruction -- three per bank -- so every ds_read_u8 takes
-// ~three passes (156 of them per wave).  Reading dwords instead and picking the bytes apart costs two VALU instructions
-// per byte and tap again (the compiler's own choice for the non-volatile form: 52 us); a form that fetched each lane's
-// window with three unaligned 16-byte GLOBAL loads measured 57 us.  All three sit within 20 % of each other: the pass is
-// a 6-byte-stride gather whichever way it is served.
-constexpr int HS_ROWS = 16;                 // rows per block = 4 waves x HR
-typedef const volatile uint8_t __attribute__((address_space(3))) *lds_cv_u8;
-// a * b + c with a, b in 24 bits (|weight| < 2^22, byte < 2^8): ONE instruction.  Written as asm because the compiler
-// forms v_mad_i32_i24 from __mul24 + add in a few places only and leaves a v_mul_i32_i24 + v_add pair elsewhere.
-static __device__ __forceinline__ int mad24(int a, int b, int c)
+// ---- horizontal pass, ROWS form ----
+// With lanes along the output columns every tap is a gather at a ~6-byte stride, through the address path (gather form)
+// or across the LDS banks (the staged form of this round's first rebuild: ~3 passes per byte read).  Here the lanes of a
+// wave are 64 consecutive source ROWS and the wave walks over output columns: a tap's position and weight are then
+// WAVE-UNIFORM, and the lanes read the same byte column of 64 different rows -- with a row pitch of 4 x an odd number
+// of bytes those are 64 different banks, so a ds_read_u8 takes its 2.3 LDS cycles and no more (tools/int_rate.hip).  Per
+// tap and channel: one byte read (offset in the instruction) and ONE v_mad_i32_i24 with the weight as the scalar operand.
+// A block of 4 waves stages the span its `cols` columns touch (coalesced 16-byte global loads, every source byte crosses
+// the address path once) and the columns' weights (transposed to [column][tap]); each wave takes cols / 4 columns, and
+// the results go back through LDS (transposed there) so that they leave as 16-byte row segments.  Flipped images stage
+// the mirrored span and take a column's weights in reverse order.  One launch serves every filter width (the tap loop is
+// wave-uniform).  Measured (rocprofv3, 32 / 12 KITTI frames 1242x375, us): 640 columns (13 taps) 38 against 46.5 for the
+// staged form; 320 (25 taps) 20.6 against 28.2 (gather); 160 (49 taps) 20 against 34 (staged); 80 (95 taps) 22 against 31
+// (taps along the lanes).  Its bound is the vector ALU and the LDS together: per column and wave 39 multiply-adds, 13
+// v_readlane (8 cycles each) and ~25 instructions of bookkeeping against 43 LDS instructions.
+constexpr int HW_ROWS = 64;
+constexpr int HW_LDS_BUDGET = 40 * 1024;    // preferred LDS per block (4 blocks = 16 waves per CU)
+constexpr int HW_LDS_MAX = 64 * 1024;       // a 4-column block may take this much; beyond it the job keeps the gather form
+typedef volatile uint8_t __attribute__((address_space(3))) *lds_v_u8;
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+// a * w + c with a, w in 24 bits (|weight| < 2^22, byte < 2^8): ONE instruction, the weight in a scalar register.  Written
+// as asm because the compiler forms v_mad_i32_i24 from __mul24 + add in a few places only.
+static __device__ __forceinline__ int mad24s(int a, int w, int c)
 {
     int d;
-    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(w), "v"(c));
     return d;
 }
-typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
-template <int KT, bool FLIP>
-static __device__ __forceinline__ void resample_h_staged(const ResampleJob &J, uint8_t *lds, int pitch_max)
+template <bool FLIP>
+static __device__ __forceinline__ void resample_h_rows(const PackedJob &J, const PlanX &X, int in_h, uint8_t *lds)
 {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int xo0 = blockIdx.x * 64, yb = blockIdx.y * HS_ROWS;
-    const int xl = min(xo0 + 63, J.out_w - 1);
-    const int last = J.in_w - 1;
+    const int lg = X.lg_cols, cols = 1 << lg, pitch = X.pitch;
+    const int xo0 = blockIdx.x << lg, yb = blockIdx.y * HW_ROWS;
+    const int xl = min(xo0 + cols, X.out_w) - 1;
+    const int last = X.in_w - 1;
     // first / last source pixel the block's columns tap (bounds are monotonic in the column)
-    const int lo_min = J.xbounds[2 * xo0], hi_max = J.xbounds[2 * xl] + J.xbounds[2 * xl + 1] - 1;
+    const int lo_min = X.bounds[2 * xo0], hi_max = X.bounds[2 * xl] + X.bounds[2 * xl + 1] - 1;
     const int px_lo = FLIP ? last - hi_max : lo_min, px_hi = FLIP ? last - lo_min : hi_max;
     const int a0 = (3 * px_lo) & ~15;
-    const int nch = min((3 * px_hi + 3 - a0 + 15) >> 4, pitch_max >> 4);
-    const int pitch = nch << 4;
-    const unsigned total = (unsigned)J.in_h * (unsigned)J.in_stride;          // bytes of the image's rows (its slot may be larger)
-    for (int i = tid; i < HS_ROWS * nch; i += 256) {
-        const int r = i / nch, ch = i - r * nch;
-        const int y = min(yb + r, J.in_h - 1);
-        const unsigned off = (unsigned)y * (unsigned)J.in_stride + (unsigned)(a0 + 16 * ch);
-        u32x4_t v;
-        if (off + 16u <= total) {
-            __builtin_memcpy(&v, J.src + off, 16);                             // one unaligned global_load_dwordx4
-        } else {                                                               // the image's last bytes: nothing past them is read
-            uint8_t b[16];
+    const int nch = min((3 * px_hi + 3 - a0 + 15) >> 4, (pitch - 12) >> 4);
+    const unsigned total = (unsigned)in_h * (unsigned)J.in_stride;            // bytes of the image's rows (its slot may be larger)
+    // 16 lanes per row, 16 rows per sweep (no division by run-time values anywhere in this kernel: an emulated integer
+    // division is ~40 vector instructions -- the first version spent more of them on its index arithmetic than on the taps)
+    for (int r = tid >> 4; r < HW_ROWS; r += 16) {
+        const int y = min(yb + r, in_h - 1);
+        const unsigned row_off = (unsigned)y * (unsigned)J.in_stride + (unsigned)a0;
+        for (int ch = tid & 15; ch < nch; ch += 16) {
+            const unsigned off = row_off + 16u * (unsigned)ch;
+            u32x4_t v;
+            if (off + 16u <= total) {
+                __builtin_memcpy(&v, J.src + off, 16);                         // one unaligned global_load_dwordx4
+            } else {                                                           // the image's last bytes: nothing past them is read
+                uint8_t b[16];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) b[e] = off + e < total ? J.src[off + e] : 0;
-            __builtin_memcpy(&v, b, 16);
+                for (int e = 0; e < 16; ++e) b[e] = off + e < total ? J.src[off + e] : 0;
+                __builtin_memcpy(&v, b, 16);
+            }
+            unsigned *d = reinterpret_cast<unsigned *>(lds + r * pitch + 16 * ch);  // 4-byte aligned only: the pitch is 4 x odd
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
         }
-        *reinterpret_cast<u32x4_t *>(lds + r * pitch + 16 * ch) = v;
     }
-    const bool ok = xo0 + lane < J.out_w;
-    const int xo = min(xo0 + lane, J.out_w - 1);
-    const int xmin = J.xbounds[2 * xo], n = J.xbounds[2 * xo + 1];
-    const int *k = J.xkk + xo;
-    const int px0 = FLIP ? last - xmin - (n - 1) : xmin;
-    int w[KT];
-#pragma unroll
-    for (int p = 0; p < KT; ++p) {
-        const int t = FLIP ? n - 1 - p : p;
-        w[p] = p < n ? k[(size_t)t * J.out_w] : 0;
+    // the weights of the block's columns, transposed to [column][tap] (rows of an odd number of dwords): a wave then
+    // fetches one column's taps with ONE conflict-free read, lane l <- tap l, and hands them to the scalar side with
+    // v_readlane.  (Scalar loads straight from the tap-major plan -- one per tap, each in another cache line -- measured
+    // the same 39 us: what bounds the kernel is instruction issue, not those loads' latency.)
+    const int opitch = cols + 4;                                               // (cols + 4) / 4 is odd: the lanes' result bytes fall in 64 banks
+    uint8_t *s_out = lds + HW_ROWS * pitch;                                    // [3][HW_ROWS][opitch]
+    int *s_w = reinterpret_cast<int *>(s_out + 3 * HW_ROWS * opitch);          // [cols][kp]
+    const int ks = X.ksize, kp = ks | 1;
+    for (int i = tid; i < ks << lg; i += 256) {
+        const int t = i >> lg, xc = i & (cols - 1);
+        s_w[xc * kp + t] = X.kk[(unsigned)(t * X.out_w + min(xo0 + xc, X.out_w - 1))];
+    }
+    const int per = cols >> 2;
+    const int xw0 = xo0 + wave * per;
+    int bx = 0, bn = 0;                                                        // lane j: the bounds of the wave's column j
+    if (lane < per && xw0 + lane < X.out_w) {
+        bx = X.bounds[2 * (xw0 + lane)];
+        bn = X.bounds[2 * (xw0 + lane) + 1];
     }
     __syncthreads();
-    const size_t plane = (size_t)J.in_h * J.out_w;
-    const uint8_t *col = lds + (3 * px0 - a0);
-    // results leave through LDS too when the block's 64 columns are whole and 16-byte aligned in the output rows: the
-    // 3 x 16 row segments of 64 bytes go out as 192 16-byte stores (3 store instructions per block instead of 48 that
-    // each write 16 scattered dwords)
-    uint8_t *s_out = lds + HS_ROWS * pitch_max;                                // [3][HS_ROWS][64]
-    const bool wide_out = J.vec4 && (J.out_w & 15) == 0 && xo0 + 64 <= J.out_w && (((size_t)J.inter) & 15) == 0 &&
-                          (plane & 15) == 0;
-#pragma unroll
-    for (int r = 0; r < HR; ++r) {
-        const int row = wave * HR + r;
-        // volatile: one ds_read_u8 per tap byte, as written.  Left alone the compiler merges the bytes into unaligned
-        // 16-byte LDS reads and picks them apart with v_mul_i32_i24_sdwa + v_add (two VALU instructions per byte and tap,
-        // ~900 per wave: the kernel then runs at the VALU's pace, 52 us -- no faster than the gather form); a byte read
-        // delivers the operand ready for ONE v_mad_i32_i24
-        const lds_cv_u8 q = (lds_cv_u8)(col + row * pitch);
+    const int nper = min(per, X.out_w - xw0);                                  // wave-uniform (may be <= 0)
+    for (int j = 0; j < nper; ++j) {
+        const int xc = wave * per + j;
+        const int xmin = __builtin_amdgcn_readlane(bx, j), n = __builtin_amdgcn_readlane(bn, j);
+        const int px0 = FLIP ? last - xmin - (n - 1) : xmin;
+        lds_v_u8 q = (lds_v_u8)(lds + lane * pitch + (3 * px0 - a0));
         int s0 = 1 << (RS_BITS - 1), s1 = s0, s2 = s0;
-        int bytes[3 * KT];
+        for (int g = 0; g < n; g += 64) {                                      // 64 taps at a time (one pass up to 64 taps)
+            const int pos = g + lane;
+            const int wv = pos < n ? s_w[xc * kp + (FLIP ? n - 1 - pos : pos)] : 0;
+            const int ng = min(64, n - g);
+            int p = 0;
+            for (; p + 4 <= ng; p += 4, q += 12) {
+                int b[12];
 #pragma unroll
-        for (int e = 0; e < 3 * KT; ++e) bytes[e] = (int)q[e];
-#pragma unroll
-        for (int p = 0; p < KT; ++p) {
-            s0 = mad24(bytes[3 * p], w[p], s0);
-            s1 = mad24(bytes[3 * p + 1], w[p], s1);
-            s2 = mad24(bytes[3 * p + 2], w[p], s2);
+                for (int e = 0; e < 12; ++e) b[e] = (int)q[e];
+                const int w0 = __builtin_amdgcn_readlane(wv, p), w1 = __builtin_amdgcn_readlane(wv, p + 1);
+                const int w2 = __builtin_amdgcn_readlane(wv, p + 2), w3 = __builtin_amdgcn_readlane(wv, p + 3);
+                s0 = mad24s(b[0], w0, s0); s1 = mad24s(b[1], w0, s1); s2 = mad24s(b[2], w0, s2);
+                s0 = mad24s(b[3], w1, s0); s1 = mad24s(b[4], w1, s1); s2 = mad24s(b[5], w1, s2);
+                s0 = mad24s(b[6], w2, s0); s1 = mad24s(b[7], w2, s1); s2 = mad24s(b[8], w2, s2);
+                s0 = mad24s(b[9], w3, s0); s1 = mad24s(b[10], w3, s1); s2 = mad24s(b[11], w3, s2);
+            }
+            for (; p < ng; ++p, q += 3) {
+                const int b0 = (int)q[0], b1 = (int)q[1], b2 = (int)q[2];
+                const int w = __builtin_amdgcn_readlane(wv, p);
+                s0 = mad24s(b0, w, s0);
+                s1 = mad24s(b1, w, s1);
+                s2 = mad24s(b2, w, s2);
+            }
         }
-        if (wide_out) {
-            s_out[(0 * HS_ROWS + row) * 64 + lane] = clip8(s0);
-            s_out[(1 * HS_ROWS + row) * 64 + lane] = clip8(s1);
-            s_out[(2 * HS_ROWS + row) * 64 + lane] = clip8(s2);
-        } else {
-            const int y = min(yb + row, J.in_h - 1);
-            const bool row_ok = ok && yb + row < J.in_h;
-            const size_t o = (size_t)y * J.out_w + xo;
-            store_bytes_packed(J.inter + o, clip8(s0), J.vec4 != 0, row_ok, lane);
-            store_bytes_packed(J.inter + plane + o, clip8(s1), J.vec4 != 0, row_ok, lane);
-            store_bytes_packed(J.inter + 2 * plane + o, clip8(s2), J.vec4 != 0, row_ok, lane);
-        }
+        s_out[(0 * HW_ROWS + lane) * opitch + xc] = clip8(s0);
+        s_out[(1 * HW_ROWS + lane) * opitch + xc] = clip8(s1);
+        s_out[(2 * HW_ROWS + lane) * opitch + xc] = clip8(s2);
     }
-    if (wide_out) {
-        __syncthreads();
-        if (tid < 3 * HS_ROWS * 4) {
-            const int seg = tid >> 2, quarter = tid & 3;                       // seg = plane * HS_ROWS + row
-            const int pl = seg / HS_ROWS, row = seg - pl * HS_ROWS;
-            if (yb + row < J.in_h)
-                *reinterpret_cast<u32x4_t *>(J.inter + pl * plane + (size_t)(yb + row) * J.out_w + xo0 + 16 * quarter) =
-                    *reinterpret_cast<const u32x4_t *>(s_out + seg * 64 + 16 * quarter);
+    __syncthreads();
+    const size_t plane = (size_t)in_h * X.out_w;
+    const bool wide = (cols & 15) == 0 && (X.out_w & 15) == 0 && (((size_t)J.inter) & 15) == 0;
+    if (wide) {                                                                // 16-byte row segments
+        const int lgs = lg - 4;
+        for (int i = tid; i < (3 * HW_ROWS) << lgs; i += 256) {
+            const int row = i >> lgs, sg = i & ((1 << lgs) - 1);               // row = plane * HW_ROWS + r
+            const int pl = row >> 6, r = row & 63;
+            if (yb + r < in_h && xo0 + 16 * sg < X.out_w) {
+                const unsigned *sp = reinterpret_cast<const unsigned *>(s_out + row * opitch + 16 * sg);
+                u32x4_t v = {sp[0], sp[1], sp[2], sp[3]};
+                *reinterpret_cast<u32x4_t *>(J.inter + pl * plane + (size_t)(yb + r) * X.out_w + xo0 + 16 * sg) = v;
+            }
+        }
+    } else if (J.flags & JOB_VEC4) {                                           // dwords (out_w % 4 == 0, 4-byte aligned planes)
+        const int lgs = lg - 2;
+        for (int i = tid; i < (3 * HW_ROWS) << lgs; i += 256) {
+            const int row = i >> lgs, sg = i & ((1 << lgs) - 1);
+            const int pl = row >> 6, r = row & 63;
+            if (yb + r < in_h && xo0 + 4 * sg < X.out_w)
+                *reinterpret_cast<unsigned *>(J.inter + pl * plane + (size_t)(yb + r) * X.out_w + xo0 + 4 * sg) =
+                    *reinterpret_cast<const unsigned *>(s_out + row * opitch + 4 * sg);
+        }
+    } else {
+        for (int i = tid; i < (3 * HW_ROWS) << lg; i += 256) {
+            const int row = i >> lg, xc = i & (cols - 1);
+            const int pl = row >> 6, r = row & 63;
+            if (yb + r < in_h && xo0 + xc < X.out_w)
+                J.inter[pl * plane + (size_t)(yb + r) * X.out_w + xo0 + xc] = s_out[row * opitch + xc];
         }
     }
 }
 
-template <int KT>
-__global__ __launch_bounds__(256) void resample_h_staged_kernel(ResampleJobs jobs, int pitch_max)
+__global__ __launch_bounds__(256) void resample_h_rows_kernel(ResampleLaunch L)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_span[];
-    const ResampleJob &J = jobs.j[blockIdx.z];
-    if (J.h_window != KT) return;
-    if ((int)blockIdx.x * 64 >= J.out_w || (int)blockIdx.y * HS_ROWS >= J.in_h) return;      // block-uniform
-    if (J.flip) resample_h_staged<KT, true>(J, s_span, pitch_max);
-    else resample_h_staged<KT, false>(J, s_span, pitch_max);
+    const PackedJob &J = L.j[blockIdx.z];
+    const PlanX &X = L.x[J.px];
+    if (X.lg_cols == HW_GATHER) return;
+    const int in_h = L.y[J.py].in_h;
+    if ((int)(blockIdx.x << X.lg_cols) >= X.out_w || (int)blockIdx.y * HW_ROWS >= in_h) return;      // block-uniform
+    if (J.flags & JOB_FLIP) resample_h_rows<true>(J, X, in_h, s_span);
+    else resample_h_rows<false>(J, X, in_h, s_span);
 }
 
-// Horizontal pass for strong reductions (65..128 taps: the 80-column scale of a 1242-wide frame has 95).  With lanes along the
-// output columns a tap load gathers at a stride of 3*in/out bytes -- 46 bytes for the 80-column scale: 64 cache lines
-// per instruction, 6 % of each used.  Here a WAVE owns one output column: each 16-lane DPP row takes one source row,
-// each lane a contiguous chunk of C taps (16*C >= taps; the row's taps are 3*n contiguous bytes), and four row-local
-// DPP adds finish the sum -- 3 reduction instructions per output instead of 18 for a whole-wave reduction.  The
-// column's weights stay in registers while the wave walks down the rows.
-constexpr int HT_ROWS = 96;            // rows per block (4 at a time)
-template <int C>
-__global__ __launch_bounds__(256) void resample_h_taps_kernel(ResampleJobs jobs)
+// ---- vertical pass ----
+// planar inter [3][in_h][out_w] -> planar [3][out_h][out_w] uint8 and / or float32 (= u8 / 255).
+// Large outputs (JOB_VEC8): a thread owns eight consecutive bytes of an output row (two dword loads per tap); the threads of
+// a block cover whole rows, 256 / (out_w / 8) of them (a 640-byte row takes 80 threads: three rows per block, 94 % of the
+// lanes busy -- the first form gave a row a whole block and left 38 % of the lanes idle in a kernel bound by the vector
+// ALU).  Per tap and byte: one v_mul_i32_i24 with the byte selected in the instruction (SDWA) and half a three-operand add,
+// instead of an extraction and a multiply-add.  Small outputs and any other shape: a thread per byte (the 24x80 scale has
+// 5760 bytes per image and 95 taps each: it needs the threads, not the width).
+static __device__ __forceinline__ int mul_byte0(unsigned v, int w)
 {
-    const ResampleJob &J = jobs.j[blockIdx.z];
-    if (J.h_taps != C) return;
-    const int lane = threadIdx.x & 63, xo = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int y0 = blockIdx.y * HT_ROWS;
-    if (xo >= J.out_w || y0 >= J.in_h) return;                         // wave-uniform
-    const int sub = lane & 15, rr = lane >> 4;
-    const int xmin = J.xbounds[2 * xo], n = J.xbounds[2 * xo + 1];
-    const int last = J.in_w - 1;
-    int w[C], off[C], sh[C];
-#pragma unroll
-    for (int j = 0; j < C; ++j) {
-        const int t = sub * C + j, tt = min(t, n - 1);                  // past the last tap: its address, weight 0
-        w[j] = t < n ? J.xkk[(size_t)t * J.out_w + xo] : 0;
-        const int px = J.flip ? last - (xmin + tt) : xmin + tt;
-        const int edge = px == last ? 1 : 0;
-        off[j] = 3 * px - edge;
-        sh[j] = 8 * edge;
-    }
-    const size_t plane = (size_t)J.in_h * J.out_w;
-    const int y1 = min(y0 + HT_ROWS, J.in_h);
-    for (int yb = y0; yb < y1; yb += 4) {                               // every lane runs every iteration (DPP below)
-        const int y = yb + rr;
-        const uint8_t *row = J.src + (size_t)min(y, J.in_h - 1) * J.in_stride;
-        int s0 = 0, s1 = 0, s2 = 0;
-#pragma unroll
-        for (int j = 0; j < C; ++j) {
-            const unsigned v = load32_unaligned(row + off[j]) >> sh[j];
-            s0 += __mul24((int)(v & 255u), w[j]);
-            s1 += __mul24((int)((v >> 8) & 255u), w[j]);
-            s2 += __mul24((int)((v >> 16) & 255u), w[j]);
-        }
-        // sum over the 16 lanes of the DPP row: lane 15 of each row ends with the total (row_shr, zero fill)
-#define MDX_ROW_SHR_ADD(d)                                                     \
-        s0 += __builtin_amdgcn_update_dpp(0, s0, 0x110 + d, 0xf, 0xf, true);   \
-        s1 += __builtin_amdgcn_update_dpp(0, s1, 0x110 + d, 0xf, 0xf, true);   \
-        s2 += __builtin_amdgcn_update_dpp(0, s2, 0x110 + d, 0xf, 0xf, true);
-        MDX_ROW_SHR_ADD(8) MDX_ROW_SHR_ADD(4) MDX_ROW_SHR_ADD(2) MDX_ROW_SHR_ADD(1)
-#undef MDX_ROW_SHR_ADD
-        if (sub == 15 && y < J.in_h) {
-            const size_t o = (size_t)y * J.out_w + xo;
-            J.inter[o] = clip8(s0 + (1 << (RS_BITS - 1)));
-            J.inter[plane + o] = clip8(s1 + (1 << (RS_BITS - 1)));
-            J.inter[2 * plane + o] = clip8(s2 + (1 << (RS_BITS - 1)));
-        }
-    }
+    int d;
+    asm("v_mul_i32_i24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(d) : "v"(v), "v"(w));
+    return d;
 }
-
-// Vertical pass: planar inter [3][in_h][out_w] -> planar [3][out_h][out_w] uint8 and / or float32 (= u8 / 255).
-// VEC = 4: a thread owns four consecutive bytes of an output row (one dword load per tap; out_w % 4 == 0 and 4-byte
-// aligned planes -- every size of the KITTI pyramids); VEC = 1: any shape.  The taps' weights are wave-uniform.
-template <int VEC>
-__global__ __launch_bounds__(256) void resample_v_kernel(ResampleJobs jobs)
+static __device__ __forceinline__ int mul_byte1(unsigned v, int w)
 {
-    const ResampleJob &J = jobs.j[blockIdx.z / 3];
+    int d;
+    asm("v_mul_i32_i24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(d) : "v"(v), "v"(w));
+    return d;
+}
+static __device__ __forceinline__ int mul_byte2(unsigned v, int w)
+{
+    int d;
+    asm("v_mul_i32_i24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(d) : "v"(v), "v"(w));
+    return d;
+}
+static __device__ __forceinline__ int mul_byte3(unsigned v, int w)
+{
+    int d;
+    asm("v_mul_i32_i24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(d) : "v"(v), "v"(w));
+    return d;
+}
+static __device__ __forceinline__ int add3(int a, int b, int c)
+{
+    int d;
+    asm("v_add3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(256) void resample_v_kernel(ResampleLaunch L)
+{
+    const PackedJob &J = L.j[blockIdx.z / 3];
     const int c = blockIdx.z % 3;
-    const int xo = (blockIdx.x * 256 + threadIdx.x) * VEC;
-    const int yo = blockIdx.y;
-    if (xo >= J.out_w || yo >= J.out_h) return;
-    if (VEC == 4 && !J.vec4) return;               // this job runs in the VEC = 1 launch
-    if (VEC == 1 && J.vec4) return;
-    const int ymin = J.ybounds[2 * yo], n = J.ybounds[2 * yo + 1];
-    const int *k = J.ykk + yo;                     // [ksize][out_h]
-    const uint8_t *p = J.inter + ((size_t)c * J.in_h + ymin) * J.out_w + xo;
-    const size_t o = ((size_t)c * J.out_h + yo) * J.out_w + xo;
-    if (VEC == 4) {
-        int s0 = 1 << (RS_BITS - 1), s1 = s0, s2 = s0, s3 = s0;
-        const size_t ps = (size_t)J.out_w, ks = (size_t)J.out_h;
+    const PlanX &X = L.x[J.px];
+    const PlanY &Y = L.y[J.py];
+    const int out_w = X.out_w, out_h = Y.out_h, in_h = Y.in_h;
+    if (J.flags & JOB_VEC8) {                      // block-uniform
+        const int tpr = out_w >> 3;                // threads per row
+        int xo, yo;
+        if (tpr >= 256) {
+            xo = (blockIdx.x * 256 + threadIdx.x) * 8;
+            yo = blockIdx.y;
+        } else {
+            if (blockIdx.x) return;
+            const int rpb = 256 / tpr;             // rows per block (block-uniform)
+            const int r = threadIdx.x / tpr;
+            xo = (threadIdx.x - r * tpr) * 8;
+            yo = blockIdx.y * rpb + r;
+            if (r >= rpb) return;
+        }
+        if (xo >= out_w || yo >= out_h) return;
+        const int ymin = Y.bounds[2 * yo], n = Y.bounds[2 * yo + 1];
+        const int *k = Y.kk + yo;                  // [ksize][out_h]
+        const uint8_t *p = J.inter + ((size_t)c * in_h + ymin) * out_w + xo;
+        const size_t o = ((size_t)c * out_h + yo) * out_w + xo;
+        int s[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] = 1 << (RS_BITS - 1);
+        const size_t ps = (size_t)out_w, ksz = (size_t)out_h;
         int t = 0;
-        for (; t + 4 <= n; t += 4, p += 4 * ps, k += 4 * ks) {         // four loads in flight
-            unsigned v[4];
-            int w[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                v[u] = *(const unsigned *)(p + u * ps);
-                w[u] = k[u * ks];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                s0 += __mul24((int)(v[u] & 255u), w[u]); s1 += __mul24((int)((v[u] >> 8) & 255u), w[u]);
-                s2 += __mul24((int)((v[u] >> 16) & 255u), w[u]); s3 += __mul24((int)(v[u] >> 24), w[u]);
-            }
+        for (; t + 2 <= n; t += 2, p += 2 * ps, k += 2 * ksz) {
+            const u32x2_t va = *reinterpret_cast<const u32x2_t *>(p), vb = *reinterpret_cast<const u32x2_t *>(p + ps);
+            const int wa = k[0], wb = k[ksz];
+            s[0] = add3(s[0], mul_byte0(va.x, wa), mul_byte0(vb.x, wb));
+            s[1] = add3(s[1], mul_byte1(va.x, wa), mul_byte1(vb.x, wb));
+            s[2] = add3(s[2], mul_byte2(va.x, wa), mul_byte2(vb.x, wb));
+            s[3] = add3(s[3], mul_byte3(va.x, wa), mul_byte3(vb.x, wb));
+            s[4] = add3(s[4], mul_byte0(va.y, wa), mul_byte0(vb.y, wb));
+            s[5] = add3(s[5], mul_byte1(va.y, wa), mul_byte1(vb.y, wb));
+            s[6] = add3(s[6], mul_byte2(va.y, wa), mul_byte2(vb.y, wb));
+            s[7] = add3(s[7], mul_byte3(va.y, wa), mul_byte3(vb.y, wb));
         }
-        for (; t < n; ++t, p += ps, k += ks) {
-            const unsigned v = *(const unsigned *)p;
-            const int w = k[0];
-            s0 += __mul24((int)(v & 255u), w); s1 += __mul24((int)((v >> 8) & 255u), w);
-            s2 += __mul24((int)((v >> 16) & 255u), w); s3 += __mul24((int)(v >> 24), w);
+        if (t < n) {
+            const u32x2_t va = *reinterpret_cast<const u32x2_t *>(p);
+            const int wa = k[0];
+            s[0] += mul_byte0(va.x, wa); s[1] += mul_byte1(va.x, wa); s[2] += mul_byte2(va.x, wa); s[3] += mul_byte3(va.x, wa);
+            s[4] += mul_byte0(va.y, wa); s[5] += mul_byte1(va.y, wa); s[6] += mul_byte2(va.y, wa); s[7] += mul_byte3(va.y, wa);
         }
-        const unsigned v0 = clip8(s0), v1 = clip8(s1), v2 = clip8(s2), v3 = clip8(s3);
-        if (J.dst_u8) *(unsigned *)(J.dst_u8 + o) = v0 | (v1 << 8) | (v2 << 16) | (v3 << 24);
-        if (J.dst_f32)
-            *(float4 *)(J.dst_f32 + o) = make_float4((float)v0 / 255.0f, (float)v1 / 255.0f, (float)v2 / 255.0f, (float)v3 / 255.0f);
+        unsigned v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = clip8(s[e]);
+        if (J.dst_u8) {
+            u32x2_t pk = {v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24), v[4] | (v[5] << 8) | (v[6] << 16) | (v[7] << 24)};
+            *reinterpret_cast<u32x2_t *>(J.dst_u8 + o) = pk;
+        }
+        if (J.dst_f32) {
+            *reinterpret_cast<float4 *>(J.dst_f32 + o) = make_float4(unit_from_byte(v[0]), unit_from_byte(v[1]), unit_from_byte(v[2]), unit_from_byte(v[3]));
+            *reinterpret_cast<float4 *>(J.dst_f32 + o + 4) = make_float4(unit_from_byte(v[4]), unit_from_byte(v[5]), unit_from_byte(v[6]), unit_from_byte(v[7]));
+        }
     } else {
+        const int xo = blockIdx.x * 256 + threadIdx.x;
+        const int yo = blockIdx.y;
+        if (xo >= out_w || yo >= out_h) return;
+        const int ymin = Y.bounds[2 * yo], n = Y.bounds[2 * yo + 1];
+        const int *k = Y.kk + yo;
+        const uint8_t *p = J.inter + ((size_t)c * in_h + ymin) * out_w + xo;
+        const size_t o = ((size_t)c * out_h + yo) * out_w + xo;
         int s = 1 << (RS_BITS - 1);
-        for (int t = 0; t < n; ++t, p += J.out_w, k += J.out_h) s += __mul24((int)p[0], k[0]);
+        int t = 0;
+        for (; t + 4 <= n; t += 4, p += 4 * (size_t)out_w, k += 4 * (size_t)out_h) {      // four loads in flight: these are the
+            int b[4], w[4];                                                              // small outputs with the long filters
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                b[u] = (int)p[(size_t)u * out_w];
+                w[u] = k[(size_t)u * out_h];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s += __mul24(b[u], w[u]);
+        }
+        for (; t < n; ++t, p += out_w, k += out_h) s += __mul24((int)p[0], k[0]);
         const uint8_t v = clip8(s);
         if (J.dst_u8) J.dst_u8[o] = v;
-        if (J.dst_f32) J.dst_f32[o] = (float)v / 255.0f;
+        if (J.dst_f32) J.dst_f32[o] = unit_from_byte(v);
     }
 }
 
@@ -513,6 +601,26 @@ __global__ __launch_bounds__(256) void jitter_apply_kernel(JitterJobs jobs)
         for (int b = 0; b < (int)gridDim.x; ++b) total += J.lsum[b];
         grey = (int)((double)total / (double)n + 0.5);
     }
+    if (slot == 4 && J.order[0] == 4 && J.order[1] == 4 && J.order[2] == 4 && J.order[3] == 4) {
+        // the empty chain (a sample without a draw in a batch where another has one): ToTensor alone, four bytes at a time
+        const unsigned total = 3u * (unsigned)n;
+        const bool vec = (((size_t)J.src) & 3) == 0 && (!J.dst_u8 || (((size_t)J.dst_u8) & 3) == 0) &&
+                         (!J.dst_f32 || (((size_t)J.dst_f32) & 15) == 0);
+        const unsigned body = vec ? total & ~3u : 0u;
+        for (unsigned i = (blockIdx.x * 256 + threadIdx.x) * 4; i < body; i += gridDim.x * 1024) {
+            const unsigned v = *reinterpret_cast<const unsigned *>(J.src + i);
+            if (J.dst_u8) *reinterpret_cast<unsigned *>(J.dst_u8 + i) = v;
+            if (J.dst_f32)
+                *reinterpret_cast<float4 *>(J.dst_f32 + i) = make_float4(unit_from_byte(v & 255u), unit_from_byte((v >> 8) & 255u),
+                                                                         unit_from_byte((v >> 16) & 255u), unit_from_byte(v >> 24));
+        }
+        for (unsigned i = body + blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+            const uint8_t v = J.src[i];
+            if (J.dst_u8) J.dst_u8[i] = v;
+            if (J.dst_f32) J.dst_f32[i] = unit_from_byte(v);
+        }
+        return;
+    }
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         RGB8 p = {J.src[i], J.src[(size_t)n + i], J.src[2 * (size_t)n + i]};
         p = jitter_ops(p, J, 0, 4, grey);
@@ -520,9 +628,9 @@ __global__ __launch_bounds__(256) void jitter_apply_kernel(JitterJobs jobs)
             J.dst_u8[i] = (uint8_t)p.r; J.dst_u8[(size_t)n + i] = (uint8_t)p.g; J.dst_u8[2 * (size_t)n + i] = (uint8_t)p.b;
         }
         if (J.dst_f32) {
-            J.dst_f32[i] = (float)p.r / 255.0f;
-            J.dst_f32[(size_t)n + i] = (float)p.g / 255.0f;
-            J.dst_f32[2 * (size_t)n + i] = (float)p.b / 255.0f;
+            J.dst_f32[i] = unit_from_byte((unsigned)p.r);
+            J.dst_f32[(size_t)n + i] = unit_from_byte((unsigned)p.g);
+            J.dst_f32[2 * (size_t)n + i] = unit_from_byte((unsigned)p.b);
         }
     }
 }
@@ -541,9 +649,9 @@ __global__ __launch_bounds__(256) void color_convert_kernel(const uint8_t *src, 
     dst[i] = (uint8_t)o.r; dst[n + i] = (uint8_t)o.g; dst[2 * n + i] = (uint8_t)o.b;
 }
 
-// ToTensor (kitti_mono.py:283,351): float32(byte) / 255 with the IEEE divide ToTensor's CPU division performs (a
+// ToTensor (kitti_mono.py:283,351): float32(byte) / 255 as the IEEE division ToTensor's CPU kernel performs (a bare
 // multiplication by the rounded reciprocal -- what a generic tensor / scalar kernel does -- is off by one ulp for 126 of
-// the 256 byte values).  16 bytes per thread: one 16-byte load, four 16-byte stores; the tail byte by byte.
+// the 256 byte values; unit_from_byte adds the one correction step that makes it exact).  16 bytes per thread: one 16-byte load, four 16-byte stores; the tail byte by byte.
 __global__ __launch_bounds__(256) void to_tensor_kernel(const uint8_t *__restrict__ src, float *__restrict__ dst, size_t n)
 {
     const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 16;
@@ -554,14 +662,14 @@ __global__ __launch_bounds__(256) void to_tensor_kernel(const uint8_t *__restric
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             float4 o;
-            o.x = (float)(w[k] & 255u) / 255.0f;
-            o.y = (float)((w[k] >> 8) & 255u) / 255.0f;
-            o.z = (float)((w[k] >> 16) & 255u) / 255.0f;
-            o.w = (float)(w[k] >> 24) / 255.0f;
+            o.x = unit_from_byte(w[k] & 255u);
+            o.y = unit_from_byte((w[k] >> 8) & 255u);
+            o.z = unit_from_byte((w[k] >> 16) & 255u);
+            o.w = unit_from_byte(w[k] >> 24);
             *reinterpret_cast<float4 *>(dst + i + 4 * k) = o;
         }
     } else {
-        for (size_t k = i; k < n && k < i + 16; ++k) dst[k] = (float)src[k] / 255.0f;
+        for (size_t k = i; k < n && k < i + 16; ++k) dst[k] = unit_from_byte(src[k]);
     }
 }
 
@@ -654,78 +762,96 @@ MDX_EXPORT int mdx_resample_lanczos_u8(const mdx_resample_job *jobs, int njobs, 
     for (int i = 0; i < njobs; ++i)
         if (int rc = validate_resample(jobs[i])) return rc;
     hipStream_t st = (hipStream_t)stream;
-    for (int first = 0; first < njobs; first += MDX_IMG_JOBS) {
-        const int n = njobs - first < MDX_IMG_JOBS ? njobs - first : MDX_IMG_JOBS;
-        ResampleJobs a;
-        memset(&a, 0, sizeof(a));
-        int max_in_h = 0, min_in_h = 1 << 30, max_out_w = 0, max_out_h = 0, n4 = 0, n_gather = 0, cols_out_w = 0, taps_out_w = 0;
-        unsigned taps_used = 0, win_used = 0;
-        int win_pitch[5] = {0, 0, 0, 0, 0};
 #ifdef MDX_DEV_SWITCHES      // A/B builds only (build.py MDX_BUILD_DEFINES=-DMDX_DEV_SWITCHES): the shipped library never reads the environment
-        const bool force_cols = getenv("MDX_RESAMPLE_COLUMNS") != nullptr;
-        const bool force_gather = getenv("MDX_RESAMPLE_GATHER") != nullptr;
-        const bool force_staged = getenv("MDX_RESAMPLE_STAGED") != nullptr;
+    const bool no_rows = getenv("MDX_RESAMPLE_NO_ROWS") != nullptr;
+    const int rows_budget = getenv("MDX_RESAMPLE_ROWS_LDS") ? atoi(getenv("MDX_RESAMPLE_ROWS_LDS")) : HW_LDS_BUDGET;
+    const int rows_cols_max = getenv("MDX_RESAMPLE_ROWS_COLS") ? atoi(getenv("MDX_RESAMPLE_ROWS_COLS")) : 64;
 #else
-        const bool force_cols = false, force_gather = false, force_staged = false;
+    const bool no_rows = false;
+    const int rows_budget = HW_LDS_BUDGET, rows_cols_max = 64;
 #endif
-        for (int i = 0; i < n; ++i) {
-            static_cast<mdx_resample_job &>(a.j[i]) = jobs[first + i];
-            ResampleJob &J = a.j[i];
-            J.vec4 = J.out_w % 4 == 0 && aligned(J.inter, 4) && (!J.dst_u8 || aligned(J.dst_u8, 4)) &&
-                     (!J.dst_f32 || aligned(J.dst_f32, 16));
-            n4 += J.vec4;
-            // horizontal form by filter width (measured on 12 KITTI frames, columns / taps form: 25 taps 28 / 45 us,
-            // 49 taps 36 / 43 us, 95 taps 82 / 31 us): chunked taps for 65..128 taps, lanes along the columns otherwise
-            const int ks = J.xksize;
-            J.h_taps = force_cols || ks <= 64 || ks > 128 ? 0 : (ks <= 96 ? 6 : 8);
-            // staged form where it measured faster than the gather form (32 / 12 KITTI frames, rocprofv3): 13 taps 47.7 us
-            // against 58, 49 taps 33.7 against 36; at 25 taps the gather form wins (28.5 against 30.8) and keeps the job;
-            // tiny sources keep the gather form too
-            J.h_window = (J.h_taps || force_gather || J.in_w < 64) ? 0
-                         : (ks <= 13 ? 13 : (ks <= 16 ? 16 : (ks <= 26 ? (force_staged ? 26 : 0) : (ks <= 49 ? 49 : (ks <= 53 ? 53 : 0)))));
-            if (J.h_window) {
-                const int slot = J.h_window == 13 ? 0 : (J.h_window == 16 ? 1 : (J.h_window == 26 ? 2 : (J.h_window == 49 ? 3 : 4)));
-                const double scale = (double)J.in_w / J.out_w;
-                const int span_px = (int)ceil(63.0 * scale) + ks + 2;
-                const int pitch = ((3 * span_px + 16 + 15) / 16) * 16;
-                if (HS_ROWS * pitch > 60 * 1024) {
-                    J.h_window = 0;                      // (cannot happen for <= 53 taps: scale < 9, span < 640 pixels)
-                } else {
-                    win_used |= 1u << slot;
-                    win_pitch[slot] = pitch > win_pitch[slot] ? pitch : win_pitch[slot];
+    // long filters first: their blocks run longest (95 taps for the 80-column scale of a KITTI frame), dispatched last they
+    // are the launch's tail (measured: vertical pass of a batch 62 us in caller order)
+    std::vector<int> order(njobs);
+    for (int i = 0; i < njobs; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int u, int v) {
+        return jobs[u].xksize + jobs[u].yksize > jobs[v].xksize + jobs[v].yksize;
+    });
+    int first = 0;
+    while (first < njobs) {
+        ResampleLaunch a;
+        memset(&a, 0, sizeof(a));
+        int nx = 0, ny = 0, n = 0;
+        int rows_lds = 0, rows_gx = 0, n_rows = 0, gather_w = 0, max_in_h = 0;
+        int v8_gx = 0, v8_gy = 0, v1_gx = 0, v1_gy = 0;
+        for (; first + n < njobs && n < IMG_JOBS; ++n) {
+            const mdx_resample_job &S = jobs[order[first + n]];
+            int ix = 0, iy = 0;
+            while (ix < nx && !(a.x[ix].bounds == S.xbounds && a.x[ix].kk == S.xkk && a.x[ix].in_w == S.in_w && a.x[ix].out_w == S.out_w)) ++ix;
+            while (iy < ny && !(a.y[iy].bounds == S.ybounds && a.y[iy].kk == S.ykk && a.y[iy].in_h == S.in_h && a.y[iy].out_h == S.out_h)) ++iy;
+            if (ix == IMG_PLANS || iy == IMG_PLANS) break;          // a 17th plan: this job starts the next launch
+            if (ix == nx) {
+                PlanX &X = a.x[nx++];
+                X.bounds = S.xbounds; X.kk = S.xkk; X.in_w = S.in_w; X.out_w = S.out_w; X.ksize = S.xksize;
+                // rows form: the widest block (64, 32, ... 4 columns) whose staged span + result tile + weights fit the LDS
+                // budget (measured on 1242 -> 640: 32 columns 38 us, 16 columns 45 us); gather form when even 4 do not fit
+                X.lg_cols = HW_GATHER;
+                const double scale = (double)S.in_w / S.out_w;
+                for (int lg = 6; lg >= 2 && !no_rows && X.lg_cols == HW_GATHER; --lg) {
+                    const int cw = 1 << lg;
+                    if (cw > rows_cols_max) continue;
+                    const int span_px = (int)ceil((cw - 1) * scale) + S.xksize + 2;
+                    const int pitch = ((3 * span_px + 16 + 15) / 16) * 16 + 12;          // pitch / 4 is odd
+                    const int lds = HW_ROWS * pitch + 3 * HW_ROWS * (cw + 4) + 4 * cw * (S.xksize | 1);
+                    if (lds <= rows_budget || (lg == 2 && lds <= HW_LDS_MAX)) {
+                        X.lg_cols = (uint8_t)lg;
+                        X.pitch = (uint16_t)pitch;
+                    }
                 }
             }
-            if (J.h_taps) {
-                taps_used |= J.h_taps == 6 ? 4u : 8u;
-                taps_out_w = J.out_w > taps_out_w ? J.out_w : taps_out_w;
-            } else {
-                cols_out_w = J.out_w > cols_out_w ? J.out_w : cols_out_w;
+            if (iy == ny) {
+                PlanY &Y = a.y[ny++];
+                Y.bounds = S.ybounds; Y.kk = S.ykk; Y.in_h = S.in_h; Y.out_h = S.out_h; Y.ksize = S.yksize;
             }
-            n_gather += (!J.h_taps && !J.h_window) ? 1 : 0;
-            max_in_h = J.in_h > max_in_h ? J.in_h : max_in_h;
-            min_in_h = J.in_h < min_in_h ? J.in_h : min_in_h;
-            max_out_w = J.out_w > max_out_w ? J.out_w : max_out_w;
-            max_out_h = J.out_h > max_out_h ? J.out_h : max_out_h;
+            const PlanX &X = a.x[ix];
+            PackedJob &J = a.j[n];
+            J.src = S.src; J.inter = S.inter; J.dst_u8 = S.dst_u8; J.dst_f32 = S.dst_f32; J.in_stride = S.in_stride;
+            J.px = (uint8_t)ix; J.py = (uint8_t)iy;
+            const bool vec4 = S.out_w % 4 == 0 && aligned(S.inter, 4);
+            const bool vec8 = S.out_w % 8 == 0 && aligned(S.inter, 8) && (!S.dst_u8 || aligned(S.dst_u8, 8)) &&
+                              (!S.dst_f32 || aligned(S.dst_f32, 16)) && S.out_w * S.out_h >= 16384;
+            J.flags = (uint8_t)((S.flip ? JOB_FLIP : 0) | (vec4 ? JOB_VEC4 : 0) | (vec8 ? JOB_VEC8 : 0));
+            if (X.lg_cols != HW_GATHER) {
+                const int cw = 1 << X.lg_cols;
+                const int lds = HW_ROWS * X.pitch + 3 * HW_ROWS * (cw + 4) + 4 * cw * (S.xksize | 1);
+                rows_lds = lds > rows_lds ? lds : rows_lds;
+                const int gx = (S.out_w + cw - 1) / cw;
+                rows_gx = gx > rows_gx ? gx : rows_gx;
+                ++n_rows;
+            } else {
+                gather_w = S.out_w > gather_w ? S.out_w : gather_w;
+            }
+            max_in_h = S.in_h > max_in_h ? S.in_h : max_in_h;
+            if (vec8) {
+                const int tpr = S.out_w / 8;
+                const int gx = tpr >= 256 ? (tpr + 255) / 256 : 1;
+                const int gy = tpr >= 256 ? S.out_h : (S.out_h + 256 / tpr - 1) / (256 / tpr);
+                v8_gx = gx > v8_gx ? gx : v8_gx;
+                v8_gy = gy > v8_gy ? gy : v8_gy;
+            } else {
+                const int gx = (S.out_w + 255) / 256;
+                v1_gx = gx > v1_gx ? gx : v1_gx;
+                v1_gy = S.out_h > v1_gy ? S.out_h : v1_gy;
+            }
         }
-        const dim3 cg((cols_out_w + 63) / 64, (max_in_h + 4 * HR - 1) / (4 * HR), n);
-        if (n_gather) hipLaunchKernelGGL(resample_h_kernel, cg, dim3(256), 0, st, a);          // gather-form jobs
-        // staged-form jobs: one launch per tap count; LDS = 16 rows x the widest span of 64 columns among the jobs
-        // (span <= 63 * scale + ksize + 1 pixels; + 16 bytes for the alignment of its start, rounded up to 16)
-#define MDX_STAGED_LAUNCH(bit, KTV)                                                                              \
-        if (win_used & bit) {                                                                                    \
-            const int pitch = win_pitch[KTV == 13 ? 0 : (KTV == 16 ? 1 : (KTV == 26 ? 2 : (KTV == 49 ? 3 : 4)))]; \
-            hipLaunchKernelGGL(resample_h_staged_kernel<KTV>, cg, dim3(256), (size_t)HS_ROWS * pitch + 3 * HS_ROWS * 64, st, a, pitch); \
-        }
-        MDX_STAGED_LAUNCH(1u, 13) MDX_STAGED_LAUNCH(2u, 16) MDX_STAGED_LAUNCH(4u, 26) MDX_STAGED_LAUNCH(8u, 49)
-        MDX_STAGED_LAUNCH(16u, 53)
-#undef MDX_STAGED_LAUNCH
-        const dim3 tg((taps_out_w + 3) / 4, (max_in_h + HT_ROWS - 1) / HT_ROWS, n);
-        if (taps_used & 4u) hipLaunchKernelGGL(resample_h_taps_kernel<6>, tg, dim3(256), 0, st, a);
-        if (taps_used & 8u) hipLaunchKernelGGL(resample_h_taps_kernel<8>, tg, dim3(256), 0, st, a);
-        if (n4)
-            hipLaunchKernelGGL(resample_v_kernel<4>, dim3((max_out_w + 1023) / 1024, max_out_h, 3 * n), dim3(256), 0, st, a);
-        if (n4 < n)
-            hipLaunchKernelGGL(resample_v_kernel<1>, dim3((max_out_w + 255) / 256, max_out_h, 3 * n), dim3(256), 0, st, a);
+        if (n_rows)
+            hipLaunchKernelGGL(resample_h_rows_kernel, dim3(rows_gx, (max_in_h + HW_ROWS - 1) / HW_ROWS, n), dim3(256),
+                               (size_t)rows_lds, st, a);
+        if (n_rows < n)
+            hipLaunchKernelGGL(resample_h_kernel, dim3((gather_w + 63) / 64, (max_in_h + 4 * HR - 1) / (4 * HR), n), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(resample_v_kernel, dim3(v8_gx > v1_gx ? v8_gx : v1_gx, v8_gy > v1_gy ? v8_gy : v1_gy, 3 * n), dim3(256), 0,
+                           st, a);
+        first += n;
     }
     return check_launch();
 }
@@ -747,8 +873,8 @@ MDX_EXPORT int mdx_color_jitter_u8(const mdx_jitter_job *jobs, int njobs, void *
         }
     }
     hipStream_t st = (hipStream_t)stream;
-    for (int first = 0; first < njobs; first += MDX_IMG_JOBS) {
-        const int n = njobs - first < MDX_IMG_JOBS ? njobs - first : MDX_IMG_JOBS;
+    for (int first = 0; first < njobs; first += MDX_JITTER_JOBS) {
+        const int n = njobs - first < MDX_JITTER_JOBS ? njobs - first : MDX_JITTER_JOBS;
         JitterJobs a;
         memset(&a, 0, sizeof(a));
         int max_px = 0;

@@ -21,7 +21,6 @@ import torch
 
 from . import _lib
 
-IMG_JOBS = 32
 JITTER_PARTIALS = 128      # MDX_JITTER_PARTIALS
 
 
@@ -59,7 +58,9 @@ class plan_cache(object):
             kk = np.zeros((ksize, key[1]), np.int32)          # tap-major (include/mdx.h)
             _lib.check(lib.mdx_resample_plan(key[0], key[1], bounds.ctypes.data_as(C.c_void_p),
                                              kk.ctypes.data_as(C.c_void_p)), "mdx_resample_plan")
-            self.plans[key] = (ksize, torch.from_numpy(bounds).to(self.device), torch.from_numpy(kk).to(self.device))
+            tb, tk = torch.from_numpy(bounds).to(self.device), torch.from_numpy(kk).to(self.device)
+            # (ksize, bounds, kk, their device addresses): a batch asks for ~150 of these, data_ptr() is not free
+            self.plans[key] = (ksize, tb, tk, tb.data_ptr(), tk.data_ptr())
             # a plan outlives the call and may next be used from another stream (prefetcher / step): finish its upload now
             torch.cuda.current_stream(self.device).synchronize()
         return self.plans[key]
@@ -77,21 +78,28 @@ def resize_lanczos_multi(plans, sources, sizes, flips, outs):
         if src.dim() != 4 or src.shape[0] != N or src.shape[3] != 3 or len(flips) != N:
             raise _lib.MdxError("resize_lanczos: src [N,h,w,3] with N sizes and N flips expected")
     dev = sources[0].device
-    jobs = np.zeros(N * len(outs), RESAMPLE_JOB)
-    results, keep, scratch = [], [], 0
+    O = len(outs)
+    jobs = np.zeros((O, N), RESAMPLE_JOB)
+    hl, wl = [int(s[0]) for s in sizes], [int(s[1]) for s in sizes]
+    uh, uw = sorted(set(hl)), sorted(set(wl))                 # a batch has one to five distinct frame sizes
+    hinv, winv = [uh.index(h) for h in hl], [uw.index(w) for w in wl]
+    if uh[0] <= 0 or uw[0] <= 0:
+        raise _lib.MdxError("resize_lanczos: empty image in %s" % (sizes,))
+    scratch = 0
     for (si, (oh, ow), want_u8, want_f32) in outs:
         scratch += N * 3 * sources[si].shape[1] * int(ow)
     inter = torch.empty(scratch, dtype=torch.uint8, device=dev)
-    hs = np.array([int(s[0]) for s in sizes], np.int64)
-    ws = np.array([int(s[1]) for s in sizes], np.int64)
-    fl = np.array([int(bool(f)) for f in flips], np.int32)
-    idx = np.arange(N, dtype=np.uint64)
+    inter_ptr = inter.data_ptr()
+    # per output: base address and per-image step of every pointer column; per (output, distinct size): the plan.  The
+    # columns of all outputs are then filled with a handful of array operations (a batch is 72 jobs: filled output by
+    # output, field by field, this function took as long on the host as its kernels on the GPU)
+    results, cols, xpl, ypl = [], [], [], []
     at = 0
-    for o, (si, (oh, ow), want_u8, want_f32) in enumerate(outs):
+    for (si, (oh, ow), want_u8, want_f32) in outs:
         src = sources[si]
         hmax, wmax = src.shape[1], src.shape[2]
         oh, ow = int(oh), int(ow)
-        if hs.min() <= 0 or ws.min() <= 0 or hs.max() > hmax or ws.max() > wmax:
+        if uh[-1] > hmax or uw[-1] > wmax:
             raise _lib.MdxError("resize_lanczos: an image of %s does not fit its %dx%d slot" % (sizes, hmax, wmax))
         if torch.is_tensor(want_u8):
             u8, want_u8 = want_u8, True
@@ -102,20 +110,26 @@ def resize_lanczos_multi(plans, sources, sizes, flips, outs):
             u8 = torch.empty(N, 3, oh, ow, dtype=torch.uint8, device=dev) if want_u8 else None
         f32 = torch.empty(N, 3, oh, ow, dtype=torch.float32, device=dev) if want_f32 else None
         results.append((u8, f32))
-        j = jobs[o * N:(o + 1) * N]
-        xp = [plans.get(int(w), ow) for w in ws]
-        yp = [plans.get(int(h), oh) for h in hs]
-        keep += [xp, yp]
-        j["src"] = src.data_ptr() + idx * np.uint64(hmax * wmax * 3)
-        j["xbounds"], j["xkk"] = [p[1].data_ptr() for p in xp], [p[2].data_ptr() for p in xp]
-        j["ybounds"], j["ykk"] = [p[1].data_ptr() for p in yp], [p[2].data_ptr() for p in yp]
-        j["inter"] = inter.data_ptr() + at + idx * np.uint64(3 * hmax * ow)
+        cols.append((src.data_ptr(), hmax * wmax * 3, inter_ptr + at, 3 * hmax * ow,
+                     u8.data_ptr() if want_u8 else 0, 3 * oh * ow if want_u8 else 0,
+                     f32.data_ptr() if want_f32 else 0, 12 * oh * ow if want_f32 else 0, 3 * wmax, oh, ow))
         at += N * 3 * hmax * ow
-        j["dst_u8"] = u8.data_ptr() + idx * np.uint64(3 * oh * ow) if want_u8 else 0
-        j["dst_f32"] = f32.data_ptr() + idx * np.uint64(12 * oh * ow) if want_f32 else 0
-        j["in_h"], j["in_w"], j["in_stride"], j["flip"] = hs, ws, 3 * wmax, fl
-        j["out_h"], j["out_w"] = oh, ow
-        j["xksize"], j["yksize"] = [p[0] for p in xp], [p[0] for p in yp]
+        xpl.append([plans.get(w, ow) for w in uw])
+        ypl.append([plans.get(h, oh) for h in uh])
+    c = np.array(cols, dtype=np.uint64)                                        # [O, 11]
+    idx = np.arange(N, dtype=np.uint64)[None, :]
+    jobs["src"] = c[:, 0:1] + idx * c[:, 1:2]
+    jobs["inter"] = c[:, 2:3] + idx * c[:, 3:4]
+    jobs["dst_u8"] = c[:, 4:5] + idx * c[:, 5:6]
+    jobs["dst_f32"] = c[:, 6:7] + idx * c[:, 7:8]
+    jobs["in_stride"], jobs["out_h"], jobs["out_w"] = c[:, 8:9], c[:, 9:10], c[:, 10:11]
+    jobs["in_h"], jobs["in_w"] = np.array(hl, np.int32)[None, :], np.array(wl, np.int32)[None, :]
+    jobs["flip"] = np.array([int(bool(f)) for f in flips], np.int32)[None, :]
+    xa = np.array([[(p[3], p[4], p[0]) for p in row] for row in xpl], dtype=np.uint64)[:, winv]     # [O, N, 3]
+    ya = np.array([[(p[3], p[4], p[0]) for p in row] for row in ypl], dtype=np.uint64)[:, hinv]
+    jobs["xbounds"], jobs["xkk"], jobs["xksize"] = xa[:, :, 0], xa[:, :, 1], xa[:, :, 2]
+    jobs["ybounds"], jobs["ykk"], jobs["yksize"] = ya[:, :, 0], ya[:, :, 1], ya[:, :, 2]
+    jobs = jobs.reshape(-1)
     _lib.check(_lib.lib().mdx_resample_lanczos_u8(jobs.ctypes.data_as(C.c_void_p), len(jobs), _lib.stream()),
                "mdx_resample_lanczos_u8")
     inter.record_stream(torch.cuda.current_stream(dev))
@@ -147,10 +161,10 @@ def color_jitter(src_u8, params, out=None):
     jobs["dst_f32"] = out.data_ptr() + t * np.uint64(12 * h * w)
     jobs["lsum"] = lsum.data_ptr() + np.arange(len(todo), dtype=np.uint64) * np.uint64(8 * JITTER_PARTIALS)
     jobs["h"], jobs["w"] = h, w
-    for i, n in enumerate(todo):
-        order, b, c, s, hue = params[n]
-        jobs["order"][i] = [int(order[k]) if k < len(order) else 4 for k in range(4)]
-        jobs["hue_shift"][i], jobs["brightness"][i], jobs["contrast"][i], jobs["saturation"][i] = int(hue), b, c, s
+    sel = [params[n] for n in todo]
+    jobs["order"] = [(list(q[0]) + [4, 4, 4, 4])[:4] for q in sel]
+    jobs["brightness"], jobs["contrast"], jobs["saturation"] = [q[1] for q in sel], [q[2] for q in sel], [q[3] for q in sel]
+    jobs["hue_shift"] = [int(q[4]) for q in sel]
     if not out.is_contiguous() or out.shape != (N, 3, h, w) or out.dtype != torch.float32:
         raise _lib.MdxError("color_jitter: out must be a contiguous float32 [N,3,h,w] tensor")
     _lib.check(_lib.lib().mdx_color_jitter_u8(jobs.ctypes.data_as(C.c_void_p), len(todo), _lib.stream()),

@@ -334,8 +334,10 @@ int mdx_depth_monitor(const float *pred, int B, int h, int w, const float *gt, i
  * for every scale, ColorJitter, ToTensor) and kitti_mono.py:302-303 (FLIP_LEFT_RIGHT); same in kitti_stereo.py.
  * Bit-exact with Pillow (Resample.c, Blend.c, Convert.c, ImageEnhance.py) -- uint8 results, float32 = u8 / 255.
  * Jobs are HOST arrays of plain structs whose pointers are DEVICE pointers (except where noted); they are passed to the
- * kernels by value, MDX_IMG_JOBS per launch, so the caller may free or reuse the array on return. */
-#define MDX_IMG_JOBS 32
+ * kernels by value (resampling: packed, MDX_IMG_JOBS jobs sharing at most 16 plans per axis per launch; jitter:
+ * MDX_JITTER_JOBS per launch), so the caller may free or reuse the array on return.  A call may hold any number of jobs. */
+#define MDX_IMG_JOBS 72
+#define MDX_JITTER_JOBS 56
 #define MDX_JITTER_PARTIALS 128
 
 /* taps per output sample of the Lanczos-3 plan in_size -> out_size (2*ceil(3*max(in/out,1)) + 1) */

@@ -58,7 +58,8 @@ def _pil_resize(img, oh, ow, flip):
     dict(sizes=[(48, 64)], out=(48, 64)),                                                  # identity plan
     dict(sizes=[(50, 50)], out=(50, 25)),
     dict(sizes=[(5, 2), (4, 3), (1, 2)], out=(3, 2)),                                      # narrowest sources, odd rows
-    dict(sizes=[(33, 47)] * 37, out=(16, 24)),                                             # > MDX_IMG_JOBS jobs
+    dict(sizes=[(33, 47)] * 75, out=(16, 24)),                                             # > MDX_IMG_JOBS jobs: two launches
+    dict(sizes=[(20 + (i % 3), 40 + i) for i in range(19)], out=(8, 16)),                  # 19 plans per axis > 16 per launch
 ])
 def test_resize_lanczos_bit_exact(G, IP, case):
     rng = np.random.default_rng(len(case["sizes"]) * 1000 + case["out"][1])
@@ -75,29 +76,24 @@ def test_resize_lanczos_bit_exact(G, IP, case):
         assert np.array_equal(f32[n].view(np.uint32), orc.to_tensor(ref).view(np.uint32)), "ToTensor %d" % n
 
 
-def test_resize_both_horizontal_forms_agree(G, IP, monkeypatch):
-    """strong reductions take the chunked-taps form of the horizontal pass (a wave per output column), the others the
-    lanes-along-columns form; MDX_RESAMPLE_COLUMNS forces the latter everywhere: same bytes.  Filter widths 25, 49, 95
-    (the KITTI pyramid), 33, 65 and 97 (first widths of the two chunk sizes), 129 (beyond the taps form), with flips."""
+def test_resize_filter_widths(G, IP):
+    """the rows form of the horizontal pass over the filter widths of the KITTI pyramid (25, 49, 95 taps) and around its
+    tap-group boundaries (33, 65, 97, 129 taps: one and several 64-tap groups, blocks of 16 ... 4 columns), with flips."""
     rng = np.random.default_rng(78)
     plans = IP.plan_cache("cuda:0")
     cases = [((375, 1242), (96, 320)), ((375, 1242), (48, 160)), ((375, 1242), (24, 80)), ((21, 1226), (21, 230)),
-             ((9, 1000), (9, 94)), ((9, 1000), (7, 63)), ((5, 1300), (5, 61))]
+             ((9, 1000), (9, 94)), ((9, 1000), (7, 63)), ((5, 1300), (5, 61)), ((70, 900), (33, 17))]
     for (h, w), out in cases:
         imgs = [_natural(rng, h, w), _natural(rng, h, w - 5)]
         sizes, flips = [(h, w), (h, w - 5)], [False, True]
         src = torch.from_numpy(_stack(imgs)).cuda()
         a = IP.resize_lanczos(plans, src, sizes, flips, out, want_u8=True)[0]
-        monkeypatch.setenv("MDX_RESAMPLE_COLUMNS", "1")
-        b = IP.resize_lanczos(plans, src, sizes, flips, out, want_u8=True)[0]
-        monkeypatch.delenv("MDX_RESAMPLE_COLUMNS")
-        assert torch.equal(a, b), ((h, w), out)
         for n in range(2):
-            assert np.array_equal(a[n].cpu().numpy(), orc.resample_lanczos(imgs[n], out[0], out[1], flips[n]).transpose(2, 0, 1))
+            assert np.array_equal(a[n].cpu().numpy(), orc.resample_lanczos(imgs[n], out[0], out[1], flips[n]).transpose(2, 0, 1)), ((h, w), out, n)
 
 
 def test_resize_wide_source(G, IP):
-    """a source 350x wider than its output (2101 taps per column)."""
+    """a source 350x wider than its output (2101 taps per column): beyond the rows form's LDS tile, the gather form."""
     rng = np.random.default_rng(77)
     img = _natural(rng, 9, 14000)
     got = IP.resize_lanczos(IP.plan_cache("cuda:0"), torch.from_numpy(img[None]).cuda(), [(9, 14000)], [True], (5, 40), want_u8=True)[0]

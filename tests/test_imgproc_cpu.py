@@ -96,3 +96,23 @@ def test_library_plan_function_equals_oracle_coefficients():
         assert np.array_equal(b, bounds) and np.array_equal(k.T, kk), (i, o)
         assert (k.sum(0) - (1 << 22)).__abs__().max() <= ks            # weights sum to one up to rounding
     assert lib.mdx_resample_ksize(0, 4) < 0 and lib.mdx_resample_plan(4, 4, None, None) < 0
+
+
+def test_unit_from_byte_sequence_is_the_ieee_quotient():
+    """csrc/imgproc.hip unit_from_byte: q0 = b * rc, r = fma(-255, q0, b), q = fma(r, rc, q0) with rc = fl32(1 / 255) equals
+    float32(b) / float32(255) for every byte -- checked in exact rational arithmetic (each fma rounds once)."""
+    from fractions import Fraction
+
+    def rnd(x):
+        g = np.float32(float(x))
+        cands = [np.nextafter(g, np.float32(-np.inf)), g, np.nextafter(g, np.float32(np.inf))]
+        return min(cands, key=lambda c: (abs(Fraction(float(c)) - x), int(c.view(np.uint32)) & 1))
+    rc = np.float32(1.0) / np.float32(255.0)
+    assert int(rc.view(np.uint32)) == 0x3B808081
+    frc = Fraction(float(rc))
+    for b in range(256):
+        q0 = rnd(Fraction(b) * frc)
+        r = rnd(Fraction(b) - 255 * Fraction(float(q0)))
+        q = rnd(Fraction(float(q0)) + Fraction(float(r)) * frc)
+        ref = np.float32(b) / np.float32(255.0)
+        assert int(q.view(np.uint32)) == int(ref.view(np.uint32)), b

@@ -80,8 +80,8 @@ def measure(samples=24, batch=12, reps=20, height=192, width=640, frames=(0, -1,
             out.update({"gpu_us_per_batch": round(us, 1), "batch": batch, "jittered_samples_in_batch": jittered,
                         "gpu_host_ms_per_batch": round(host_ms, 2), "alg_bytes_per_batch": alg,
                         "achieved_GBs": round(alg / us / 1e3, 1), "frac_of_hbm_peak": round(alg / us / 1e3 / 8000.0, 4),
-                        "kernels": "csrc/imgproc.hip: resample_h_kernel, resample_h_taps_kernel<6>, resample_v_kernel<4>, "
-                                   "jitter_mean_kernel, jitter_apply_kernel (profiles/*_imgproc_kernel_stats.txt)"})
+                        "kernels": "csrc/imgproc.hip: resample_h_rows_kernel, resample_v_kernel, jitter_mean_kernel, "
+                                   "jitter_apply_kernel: four launches per batch (profiles/*_imgproc_kernel_stats.txt)"})
         if workers > 0:
             # the DataLoader itself (worker processes, collate, pinned memory) on the cores this process may use
             from torch.utils.data import DataLoader, Dataset
