@@ -491,75 +491,117 @@ static __device__ __forceinline__ int rgb_to_L(const RGB8 &p)
 }
 
 // ImagingBlend(a, b, alpha) for one byte: float32 a + alpha*(b - a); `inside` = alpha in [0,1]
-static __device__ __forceinline__ int blend1(int a, int b, float alpha, bool inside)
+// (inside: (UINT8)t with t in [0, 255]; outside: t <= 0 ? 0 : t >= 255 ? 255 : (UINT8)t -- both are the truncated t clamped)
+static __device__ __forceinline__ int blend1(int a, int b, float alpha)
 {
     const float t = (float)a + alpha * (float)(b - a);
-    if (inside) return (int)(uint8_t)t;
-    return t <= 0.0f ? 0 : (t >= 255.0f ? 255 : (int)t);
+    return min(max((int)t, 0), 255);
+}
+
+// Convert.c's rgb2hsv / hsv2rgb, value for value, with the divisions written out: a / b as q0 = a * rcp, one residual and
+// one correction (the IEEE quotient when rcp is close enough -- these operands are small integers, the divisors 6 and 255
+// constants); fmod(x, 1) for x > 0 as x - floor(x) (exact); round() for x >= 0 as trunc + (fraction >= 0.5).  The compiler's
+// own division sequences and the library fmod made the hue step ~250 vector instructions per pixel, most of them double
+// precision, in kernels the vector ALU bounds.  tests/test_gpu_imgproc.py checks all 2^24 RGB and all 2^24 HSV triples
+// against Pillow's convert().
+static __device__ __forceinline__ float div_small(float a, float b, float rb)       // rb = v_rcp_f32(b)
+{
+    const float q0 = a * rb;
+    const float r = __builtin_fmaf(-b, q0, a);
+    return __builtin_fmaf(r, rb, q0);
+}
+static __device__ __forceinline__ double div_const(double x, double d, double rd)   // rd = fl(1 / d)
+{
+    const double q0 = x * rd;
+    const double r = __builtin_fma(-d, q0, x);
+    return __builtin_fma(r, rd, q0);
+}
+static __device__ __forceinline__ int round_pos(double x)                            // (int)round(x), x >= 0
+{
+    const double t = __builtin_trunc(x);
+    return (int)t + ((x - t) >= 0.5 ? 1 : 0);
 }
 
 static __device__ __forceinline__ RGB8 rgb2hsv(const RGB8 &p)
 {
+    // no per-pixel branches anywhere in the chain: a divergent branch costs its scalar bookkeeping in every wave (the first
+    // form spent more scalar than vector instructions); grey pixels (minc == maxc) run the arithmetic on a stand-in range
     const int maxc = max(p.r, max(p.g, p.b)), minc = min(p.r, min(p.g, p.b));
-    RGB8 o = {0, 0, maxc};
-    if (minc == maxc) return o;
-    const float cr = (float)(maxc - minc);
-    const float s = cr / (float)maxc;
-    const float rc = (float)(maxc - p.r) / cr, gc = (float)(maxc - p.g) / cr, bc = (float)(maxc - p.b) / cr;
-    float h;
-    if (p.r == maxc) h = bc - gc;
-    else if (p.g == maxc) h = (float)(2.0 + (double)rc - (double)bc);
-    else h = (float)(4.0 + (double)gc - (double)rc);
-    h = (float)fmod((double)h / 6.0 + 1.0, 1.0);
-    o.r = min(max((int)((double)h * 255.0), 0), 255);
-    o.g = min(max((int)((double)s * 255.0), 0), 255);
+    const bool grey_px = minc == maxc;
+    const float cr = grey_px ? 1.0f : (float)(maxc - minc), fm = grey_px ? 1.0f : (float)maxc;
+    const float rcr = __builtin_amdgcn_rcpf(cr);
+    const float s = div_small(cr, fm, __builtin_amdgcn_rcpf(fm));
+    // Convert.c: rc, gc, bc = (maxc - channel) / cr;  h = bc - gc | 2 + rc - bc | 4 + gc - rc  (the first in float, the
+    // others in double, rounded to float once: base + x1 - x2 in double, rounded once, is all three)
+    const bool rmax = p.r == maxc, gmax = p.g == maxc;
+    const int n1 = maxc - (rmax ? p.b : (gmax ? p.r : p.g)), n2 = maxc - (rmax ? p.g : (gmax ? p.b : p.r));
+    const double base = rmax ? 0.0 : (gmax ? 2.0 : 4.0);
+    const float x1 = div_small((float)n1, cr, rcr), x2 = div_small((float)n2, cr, rcr);
+    float h = (float)(base + (double)x1 - (double)x2);
+    const double d = div_const((double)h, 6.0, 1.0 / 6.0) + 1.0;                    // in [5/6, 2)
+    h = (float)(d - __builtin_floor(d));                                             // fmod(d, 1.0)
+    RGB8 o;
+    o.r = grey_px ? 0 : min(max((int)((double)h * 255.0), 0), 255);
+    o.g = grey_px ? 0 : min(max((int)((double)s * 255.0), 0), 255);
+    o.b = maxc;
     return o;
 }
 
 static __device__ __forceinline__ RGB8 hsv2rgb(const RGB8 &q)      // q.r = H, q.g = S, q.b = V
 {
-    const int v = q.b;
-    if (q.g == 0) return RGB8{v, v, v};
-    const double hf = (double)(float)q.r * 6.0 / 255.0;
-    const int i = (int)floor(hf);
+    const int v = q.b;                                              // (S == 0: fs = 0 and p = qq = t = v below, as Convert.c returns)
+    const double hf = div_const((double)(float)q.r * 6.0, 255.0, 1.0 / 255.0);
+    const int i = (int)__builtin_floor(hf);
     const double f = (double)(float)(hf - (double)(float)i);
-    const double fs = (double)(float)((double)(float)q.g / 255.0);
+    const double fs = (double)(float)div_const((double)(float)q.g, 255.0, 1.0 / 255.0);
     const double vf = (double)(float)v;
-    const int p = min(max((int)round(vf * (1.0 - fs)), 0), 255);
-    const int qq = min(max((int)round(vf * (1.0 - fs * f)), 0), 255);
-    const int t = min(max((int)round(vf * (1.0 - fs * (1.0 - f))), 0), 255);
-    switch (i % 6) {
-    case 0: return RGB8{v, t, p};
-    case 1: return RGB8{qq, v, p};
-    case 2: return RGB8{p, v, t};
-    case 3: return RGB8{p, qq, v};
-    case 4: return RGB8{t, p, v};
-    default: return RGB8{v, p, qq};
-    }
+    const int p = min(round_pos(vf * (1.0 - fs)), 255);
+    const int qq = min(round_pos(vf * (1.0 - fs * f)), 255);
+    const int t = min(round_pos(vf * (1.0 - fs * (1.0 - f))), 255);
+    const int k = i >= 6 ? i - 6 : i;                               // i % 6, i in 0..6
+    // k:  0 (v,t,p)  1 (q,v,p)  2 (p,v,t)  3 (p,q,v)  4 (t,p,v)  5 (v,p,q)
+    RGB8 o;
+    o.r = (k == 0 || k == 5) ? v : (k == 1 ? qq : (k == 4 ? t : p));
+    o.g = (k == 1 || k == 2) ? v : (k == 0 ? t : (k == 3 ? qq : p));
+    o.b = (k == 3 || k == 4) ? v : (k == 2 ? t : (k == 5 ? qq : p));
+    return o;
 }
 
 // the adjustments order[first..last) applied to one pixel; `grey` = Contrast's degenerate level
-static __device__ __forceinline__ RGB8 jitter_ops(RGB8 p, const mdx_jitter_job &J, int first, int last, int grey)
+template <int NP>
+static __device__ __forceinline__ void jitter_ops_n(RGB8 (&p)[NP], const mdx_jitter_job &J, int first, int last, int grey)
 {
-    for (int i = first; i < last; ++i) {
+    for (int i = first; i < last; ++i) {              // the op is the job's (wave-uniform): one scalar branch per op and NP pixels
         const int op = J.order[i];
         if (op == 0) {
-            const bool in = J.brightness >= 0.f && J.brightness <= 1.f;
-            p = RGB8{blend1(0, p.r, J.brightness, in), blend1(0, p.g, J.brightness, in), blend1(0, p.b, J.brightness, in)};
+#pragma unroll
+            for (int e = 0; e < NP; ++e)
+                p[e] = RGB8{blend1(0, p[e].r, J.brightness), blend1(0, p[e].g, J.brightness), blend1(0, p[e].b, J.brightness)};
         } else if (op == 1) {
-            const bool in = J.contrast >= 0.f && J.contrast <= 1.f;
-            p = RGB8{blend1(grey, p.r, J.contrast, in), blend1(grey, p.g, J.contrast, in), blend1(grey, p.b, J.contrast, in)};
+#pragma unroll
+            for (int e = 0; e < NP; ++e)
+                p[e] = RGB8{blend1(grey, p[e].r, J.contrast), blend1(grey, p[e].g, J.contrast), blend1(grey, p[e].b, J.contrast)};
         } else if (op == 2) {
-            const bool in = J.saturation >= 0.f && J.saturation <= 1.f;
-            const int L = rgb_to_L(p);
-            p = RGB8{blend1(L, p.r, J.saturation, in), blend1(L, p.g, J.saturation, in), blend1(L, p.b, J.saturation, in)};
+#pragma unroll
+            for (int e = 0; e < NP; ++e) {
+                const int L = rgb_to_L(p[e]);
+                p[e] = RGB8{blend1(L, p[e].r, J.saturation), blend1(L, p[e].g, J.saturation), blend1(L, p[e].b, J.saturation)};
+            }
         } else if (op == 3) {
-            RGB8 q = rgb2hsv(p);
-            q.r = (q.r + J.hue_shift) & 255;
-            p = hsv2rgb(q);
+#pragma unroll
+            for (int e = 0; e < NP; ++e) {
+                RGB8 q = rgb2hsv(p[e]);
+                q.r = (q.r + J.hue_shift) & 255;
+                p[e] = hsv2rgb(q);
+            }
         }
     }
-    return p;
+}
+static __device__ __forceinline__ RGB8 jitter_ops(RGB8 p, const mdx_jitter_job &J, int first, int last, int grey)
+{
+    RGB8 a[1] = {p};
+    jitter_ops_n<1>(a, J, first, last, grey);
+    return a[0];
 }
 
 static __device__ __forceinline__ int contrast_slot(const mdx_jitter_job &J)
@@ -575,12 +617,26 @@ __global__ __launch_bounds__(256) void jitter_mean_kernel(JitterJobs jobs)
     const mdx_jitter_job &J = jobs.j[blockIdx.y];
     const int n = J.h * J.w, slot = contrast_slot(J);
     unsigned sum = 0;
-    if (slot < 4)
-        for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    if (slot < 4) {
+        // four pixels per thread (one dword per plane) when the planes allow it, the rest pixel by pixel
+        const bool vec = (n & 3) == 0 && (((size_t)J.src) & 3) == 0;
+        const int body = vec ? n : 0;
+        for (int i = (blockIdx.x * 256 + threadIdx.x) * 4; i < body; i += gridDim.x * 1024) {
+            const unsigned r4 = *reinterpret_cast<const unsigned *>(J.src + i), g4 = *reinterpret_cast<const unsigned *>(J.src + (size_t)n + i),
+                           b4 = *reinterpret_cast<const unsigned *>(J.src + 2 * (size_t)n + i);
+            RGB8 p[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) p[e] = RGB8{(int)((r4 >> (8 * e)) & 255u), (int)((g4 >> (8 * e)) & 255u), (int)((b4 >> (8 * e)) & 255u)};
+            jitter_ops_n<4>(p, J, 0, slot, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sum += (unsigned)rgb_to_L(p[e]);
+        }
+        for (int i = body + blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
             RGB8 p = {J.src[i], J.src[(size_t)n + i], J.src[2 * (size_t)n + i]};
             p = jitter_ops(p, J, 0, slot, 0);
             sum += (unsigned)rgb_to_L(p);
         }
+    }
     __shared__ unsigned s_part[4];
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o, 64);
     if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = sum;
@@ -596,9 +652,16 @@ __global__ __launch_bounds__(256) void jitter_apply_kernel(JitterJobs jobs)
     const int n = J.h * J.w, slot = contrast_slot(J);
     // ImageEnhance.Contrast: int(sum / count + 0.5) in double
     int grey = 0;
-    if (slot < 4) {
-        unsigned long long total = 0;
-        for (int b = 0; b < (int)gridDim.x; ++b) total += J.lsum[b];
+    if (slot < 4) {                                                 // block-uniform
+        // the partial sums of pass 1 (<= MDX_JITTER_PARTIALS = 128 of them): one per thread, reduced in the block
+        __shared__ unsigned long long s_tot[2];
+        unsigned long long part = threadIdx.x < gridDim.x ? J.lsum[threadIdx.x] : 0ull;
+        if (threadIdx.x < 128) {
+            for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o, 64);
+            if ((threadIdx.x & 63) == 0) s_tot[threadIdx.x >> 6] = part;
+        }
+        __syncthreads();
+        const unsigned long long total = s_tot[0] + s_tot[1];
         grey = (int)((double)total / (double)n + 0.5);
     }
     if (slot == 4 && J.order[0] == 4 && J.order[1] == 4 && J.order[2] == 4 && J.order[3] == 4) {
@@ -621,7 +684,36 @@ __global__ __launch_bounds__(256) void jitter_apply_kernel(JitterJobs jobs)
         }
         return;
     }
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const bool vec4 = (n & 3) == 0 && (((size_t)J.src) & 3) == 0 && (!J.dst_u8 || (((size_t)J.dst_u8) & 3) == 0) &&
+                      (!J.dst_f32 || (((size_t)J.dst_f32) & 15) == 0);
+    const int body4 = vec4 ? n : 0;
+    for (int i = (blockIdx.x * 256 + threadIdx.x) * 4; i < body4; i += gridDim.x * 1024) {      // four pixels per thread
+        const unsigned r4 = *reinterpret_cast<const unsigned *>(J.src + i), g4 = *reinterpret_cast<const unsigned *>(J.src + (size_t)n + i),
+                       b4 = *reinterpret_cast<const unsigned *>(J.src + 2 * (size_t)n + i);
+        unsigned ro = 0, go = 0, bo = 0;
+        RGB8 p[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) p[e] = RGB8{(int)((r4 >> (8 * e)) & 255u), (int)((g4 >> (8 * e)) & 255u), (int)((b4 >> (8 * e)) & 255u)};
+        jitter_ops_n<4>(p, J, 0, 4, grey);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            ro |= (unsigned)p[e].r << (8 * e); go |= (unsigned)p[e].g << (8 * e); bo |= (unsigned)p[e].b << (8 * e);
+        }
+        if (J.dst_u8) {
+            *reinterpret_cast<unsigned *>(J.dst_u8 + i) = ro;
+            *reinterpret_cast<unsigned *>(J.dst_u8 + (size_t)n + i) = go;
+            *reinterpret_cast<unsigned *>(J.dst_u8 + 2 * (size_t)n + i) = bo;
+        }
+        if (J.dst_f32) {
+            *reinterpret_cast<float4 *>(J.dst_f32 + i) = make_float4(unit_from_byte(ro & 255u), unit_from_byte((ro >> 8) & 255u),
+                                                                     unit_from_byte((ro >> 16) & 255u), unit_from_byte(ro >> 24));
+            *reinterpret_cast<float4 *>(J.dst_f32 + (size_t)n + i) = make_float4(unit_from_byte(go & 255u), unit_from_byte((go >> 8) & 255u),
+                                                                                 unit_from_byte((go >> 16) & 255u), unit_from_byte(go >> 24));
+            *reinterpret_cast<float4 *>(J.dst_f32 + 2 * (size_t)n + i) = make_float4(unit_from_byte(bo & 255u), unit_from_byte((bo >> 8) & 255u),
+                                                                                     unit_from_byte((bo >> 16) & 255u), unit_from_byte(bo >> 24));
+        }
+    }
+    for (int i = body4 + blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         RGB8 p = {J.src[i], J.src[(size_t)n + i], J.src[2 * (size_t)n + i]};
         p = jitter_ops(p, J, 0, 4, grey);
         if (J.dst_u8) {

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--out", type=str, default="192x640")
     ap.add_argument("--in", dest="inp", type=str, default="375x1242")
     ap.add_argument("--jitter", action="store_true")
+    ap.add_argument("--empty", action="store_true", help="with --jitter: the empty chain (ToTensor alone) for every image")
     a = ap.parse_args()
     oh, ow = (int(v) for v in a.out.split("x"))
     h, w = (int(v) for v in a.inp.split("x"))
@@ -50,7 +51,7 @@ def main():
     print("resize %d x (%dx%d -> %dx%d): %.1f us per call, %.2f us per image; algorithmic %.1f MB -> %.0f GB/s"
           % (a.n, h, w, oh, ow, us, us / a.n, alg / 1e6, alg / us / 1e3))
     if a.jitter:
-        params = [([2, 0, 3, 1], 1.1, 0.9, 1.15, -14)] * a.n
+        params = [([4, 4, 4, 4], 1.0, 1.0, 1.0, 0) if a.empty else ([2, 0, 3, 1], 1.1, 0.9, 1.15, -14)] * a.n
         out = torch.empty(a.n, 3, oh, ow, device="cuda")
         for _ in range(3):
             imgproc.color_jitter(u8, params, out)

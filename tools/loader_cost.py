@@ -70,14 +70,38 @@ def measure(samples=24, batch=12, reps=20, height=192, width=640, frames=(0, -1,
             e1.record()
             host_ms = 1e3 * (time.perf_counter() - t0) / reps
             e1.synchronize()
-            us = 1e3 * e0.elapsed_time(e1) / reps
+            us_eager = 1e3 * e0.elapsed_time(e1) / reps
+            # the same calls captured into a hipGraph and replayed: the stage's GPU time without the host's enqueue pace
+            # (eager, ~0.2 ms of Python per call is as long as the kernels; job tables travel by value, so a capture holds
+            # everything the replay needs)
+            us = us_eager
+            try:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    prep(raw)
+                torch.cuda.current_stream().wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    keep = prep(raw)
+                g.replay()
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(reps):
+                    g.replay()
+                e1.record()
+                e1.synchronize()
+                us = 1e3 * e0.elapsed_time(e1) / reps
+                del keep
+            except RuntimeError as err:
+                out["gpu_us_per_batch_note"] = "capture failed (%s): eager figure" % (str(err).splitlines()[0][:120],)
             h, w = (int(v) for v in raw["raw_size"][0])
             # algorithmic bytes: every source byte once; float32 entries out: scale 0 of every frame, scales 1-3 of the
             # target, colour_aug of the jittered samples
             pyramid = sum((height >> s) * (width >> s) for s in range(1, 4))
             alg = batch * len(frames) * h * w * 3 + 12 * (batch * len(frames) * height * width + batch * pyramid
                                                           + jittered * len(frames) * height * width)
-            out.update({"gpu_us_per_batch": round(us, 1), "batch": batch, "jittered_samples_in_batch": jittered,
+            out.update({"gpu_us_per_batch": round(us, 1), "gpu_us_per_batch_eager_loop": round(us_eager, 1), "batch": batch, "jittered_samples_in_batch": jittered,
                         "gpu_host_ms_per_batch": round(host_ms, 2), "alg_bytes_per_batch": alg,
                         "achieved_GBs": round(alg / us / 1e3, 1), "frac_of_hbm_peak": round(alg / us / 1e3 / 8000.0, 4),
                         "kernels": "csrc/imgproc.hip: resample_h_rows_kernel, resample_v_kernel, jitter_mean_kernel, "
