@@ -60,6 +60,9 @@ def _pil_resize(img, oh, ow, flip):
     dict(sizes=[(5, 2), (4, 3), (1, 2)], out=(3, 2)),                                      # narrowest sources, odd rows
     dict(sizes=[(33, 47)] * 75, out=(16, 24)),                                             # > MDX_IMG_JOBS jobs: two launches
     dict(sizes=[(20 + (i % 3), 40 + i) for i in range(19)], out=(8, 16)),                  # 19 plans per axis > 16 per launch
+    dict(sizes=[(9, 4200), (7, 4100)], out=(8, 2112)),                                     # vertical pass: a row wider than a block (264 threads)
+    dict(sizes=[(20, 30), (19, 28)], out=(130, 136)),                                      # upscale large enough for the 8-byte vertical form, 15 rows per block
+    dict(sizes=[(40, 100)], out=(30, 36)),                                                 # out_w % 4 == 0, % 8 != 0: dword stores, byte vertical pass
 ])
 def test_resize_lanczos_bit_exact(G, IP, case):
     rng = np.random.default_rng(len(case["sizes"]) * 1000 + case["out"][1])
