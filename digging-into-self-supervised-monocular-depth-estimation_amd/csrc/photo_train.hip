@@ -500,15 +500,60 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
     const float *disp_b = pick(a.disp, scale) + (size_t)b * d.h * d.w;
     const float *P_s = pick(a.P, scale);
     const float *noise_s = pick(a.noise, scale);
-    const float *bidfi_s = pick(a.bidfi, scale);
+    // MDX_TRAIN_LATE_PICK: the per-scale output pointers (and the best-identity map) are fetched from the kernel-argument
+    // segment WHERE THEY ARE USED -- one s_load_dwordx2 at (array offset + 8 * scale), two scalar registers for a few
+    // instructions.  Held across the row loop they were loop-invariant 64-bit scalars the allocator spilled to VGPR lanes,
+    // and every use paid two v_readlane (8.5 cycles each on the vector ALU that bounds this kernel).  (Re-deriving them with
+    // pick() -- four pointer loads and a select chain -- at the use sites made it worse: 28 -> 49 spilled scalars.)
+#ifndef MDX_TRAIN_LATE_PICK
+#define MDX_TRAIN_LATE_PICK 1
+#endif
+#if MDX_TRAIN_LATE_PICK
+    const char *const kargs = (const char *)__builtin_amdgcn_kernarg_segment_ptr();     // TrainArgs is the kernel's only argument
+    const unsigned scale8 = 8u * (unsigned)scale;
+#define MDX_LATE(T, arr)                                                                                          \
+    ([&]() {                                                                                                      \
+        unsigned long long v_;                                                                                    \
+        asm volatile("s_load_dwordx2 %0, %1, %2 offset:%3\n\ts_waitcnt lgkmcnt(0)"                                \
+                     : "=s"(v_) : "s"(kargs), "s"(scale8), "n"(__builtin_offsetof(TrainArgs, arr)));              \
+        typedef __attribute__((address_space(1))) char *gp_;       /* a global pointer: saddr stores, not flat ones */ \
+        return (T)(gp_)v_;                                                                                        \
+    }())
+#else
     uint8_t *idx_s = pick(a.idx, scale);
     float *gup_s = pick(a.gup, scale);
     float *to_opt_s = pick(a.to_opt, scale);
+    const float *bidfi_l = pick(a.bidfi, scale);
+#define MDX_LATE(T, arr) ((T)MDX_LATE_##arr)
+#define MDX_LATE_idx idx_s
+#define MDX_LATE_gup gup_s
+#define MDX_LATE_to_opt to_opt_s
+#define MDX_LATE_bidfi bidfi_l
+#endif
     const float *invK_b = a.invK + b * 16;
     const float *tgt_b = a.target + (size_t)b * 3 * HW0;
+#ifndef MDX_TRAIN_LATE_FLAGS
+#define MDX_TRAIN_LATE_FLAGS 1
+#endif
+#if MDX_TRAIN_LATE_FLAGS
+    // the item's wave-uniform conditions, re-derived from one scalar WHERE THEY ARE USED (a bit test on the scalar unit):
+    // as loop-invariant booleans they lived in 64-bit lane masks, which the allocator spilled to VGPR lanes and fetched
+    // back with two v_readlane per use
+    const unsigned item_bits = ((d.flags & MDX_FLAG_AUTOMASK) ? 1u : 0u) | ((d.flags & MDX_FLAG_UPSAMPLE_PREMUL) ? 2u : 0u) |
+                               ((d.h == d.H && d.w == d.W) ? 4u : 0u);
+    auto item_bit = [&](unsigned m) {
+        unsigned v = item_bits;
+        asm volatile("" : "+s"(v));
+        return (v & m) != 0;
+    };
+#define automask item_bit(1u)
+#define premul item_bit(2u)
+#define same_res item_bit(4u)
+#else
     const bool automask = (d.flags & MDX_FLAG_AUTOMASK) != 0;
     const bool premul = (d.flags & MDX_FLAG_UPSAMPLE_PREMUL) != 0;
     const bool same_res = d.h == H && d.w == W;
+#endif
     const Norm2 nd = desc_norm(d);
 
     // ---- per-lane constants: the column ----
@@ -615,7 +660,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
             const char *tp = reinterpret_cast<const char *>(a.tstat + (size_t)b * 6 * HW) + po * 24u;
             pf_ts4 = *reinterpret_cast<const f32x4_a8 *>(tp);
             pf_ts2 = *reinterpret_cast<const float2_a4 *>(tp + 16);
-            if (automask) pf_bf = *reinterpret_cast<const u32x2_a4 *>(reinterpret_cast<const char *>(bidfi_s + (size_t)b * 2 * HW) + po * 8u);
+            if (automask) pf_bf = *reinterpret_cast<const u32x2_a4 *>(reinterpret_cast<const char *>(MDX_LATE(const float *, bidfi) + (size_t)b * 2 * HW) + po * 8u);
         } else {
             if (!automask) return;
 #pragma unroll
@@ -712,7 +757,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
             prefetch_warp_row(wr + 1);
 #if MDX_TRAIN_DEFER_GUP
             if constexpr (GRAD) {
-                if (gup_row >= 0 && out_lane) at32(gup_s + (size_t)b * HW, (unsigned)(gup_row * W + pxr)) = gup_val;
+                if (gup_row >= 0 && out_lane) at32(MDX_LATE(float *, gup) + (size_t)b * HW, (unsigned)(gup_row * W + pxr)) = gup_val;
                 gup_row = -1;
             }
 #endif
@@ -893,8 +938,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
 #endif
             if (out_lane && sr >= r0 && sr < r1) {
                 const unsigned po = (unsigned)(sr * W + pxr);
-                at32(idx_s + (size_t)b * HW, po) = (uint8_t)bi;
-                if (to_opt_s) at32(to_opt_s + (size_t)b * HW, po) = best;
+                at32(MDX_LATE(uint8_t *, idx) + (size_t)b * HW, po) = (uint8_t)bi;
+                float *const to_opt_p = MDX_LATE(float *, to_opt);
+                if (to_opt_p) at32(to_opt_p + (size_t)b * HW, po) = best;
 #if MDX_TRAIN_LOSS_LDS
                 // the cell's address from a lane id formed HERE (two v_mbcnt, volatile so that they are not hoisted): as a
                 // loop-invariant register it was the next value to be spilled
@@ -1024,7 +1070,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
         gup_val = gdepth * (-d.disp_b * depth * depth);
         gup_row = gr;
 #else
-        if (out_lane) at32(gup_s + (size_t)b * HW, (unsigned)(gr * W + pxr)) = gdepth * (-d.disp_b * depth * depth);
+        if (out_lane) at32(MDX_LATE(float *, gup) + (size_t)b * HW, (unsigned)(gr * W + pxr)) = gdepth * (-d.disp_b * depth * depth);
 #endif
         MDX_STAMP(3);   // gradient phase
         }
@@ -1032,7 +1078,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
     }
 #if MDX_TRAIN_DEFER_GUP
     if constexpr (GRAD)
-        if (gup_row >= 0 && out_lane) at32(gup_s + (size_t)b * HW, (unsigned)(gup_row * W + pxr)) = gup_val;
+        if (gup_row >= 0 && out_lane) at32(MDX_LATE(float *, gup) + (size_t)b * HW, (unsigned)(gup_row * W + pxr)) = gup_val;
 #endif
 #ifdef MDX_TRAIN_STAMPS
     if (lane == 0 && a.stamps) {
@@ -1185,6 +1231,12 @@ MDX_DEV void upsample_bwd_tile(const float *__restrict__ gout, int H, int W, flo
 // tile shape by ratio (host and device agree through these)
 static int finish_tw(int r) { return r == 2 ? 64 : (r == 4 ? 32 : 16); }
 static int finish_th(int r) { return 4; }
+#if MDX_TRAIN_LATE_FLAGS
+#undef automask
+#undef premul
+#undef same_res
+#endif
+
 
 __global__ __launch_bounds__(NT) void train_finish_kernel(FinishArgs a)
 {
