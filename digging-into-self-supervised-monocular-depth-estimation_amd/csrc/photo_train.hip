@@ -644,14 +644,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
         const int pyr = reflect(min(max(wr, -1), H), H);
         const unsigned po = (unsigned)(pyr * W + pxr);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) pf_y[c] = at32(tgt_b + (size_t)c * HW, po);
+        for (int c = 0; c < 3; ++c) {
+            // the plane's base as an opaque SCALAR: left to the compiler the plane offset is added per lane in 64 bits
+            // (v_lshl_add_u64, 8.5 cycles against 2.8 for a 32-bit add -- tools/int_rate.hip) and the load loses its
+            // scalar-base form
+            unsigned long long pv = (unsigned long long)(tgt_b + (size_t)c * HW);
+            asm volatile("" : "+s"(pv));
+            typedef __attribute__((address_space(1))) const float *gptr;      // (a GLOBAL pointer: an integer cast to a generic one
+            pf_y[c] = at32((const float *)(gptr)pv, po);                       //  would turn the load into a flat one)
+        }
         if (same_res) {
             pf_d[0] = at32(disp_b, po);
         } else {
+            // the four disparity taps at 32-bit element offsets from the (scalar) map base: row pointers formed from the
+            // per-lane row index were 64-bit VALU address arithmetic
             const UpTap ty = up_tap((float)d.h / (float)H, pyr, d.h);
-            const float *row0 = disp_b + ty.i0 * d.w, *row1 = disp_b + ty.i1 * d.w;
+            const unsigned o0 = (unsigned)(ty.i0 * d.w), o1 = (unsigned)(ty.i1 * d.w);
             const UpTap tx = tx_tap();
-            pf_d[0] = row0[tx.i0]; pf_d[1] = row0[tx.i1]; pf_d[2] = row1[tx.i0]; pf_d[3] = row1[tx.i1];
+            pf_d[0] = at32(disp_b, o0 + (unsigned)tx.i0); pf_d[1] = at32(disp_b, o0 + (unsigned)tx.i1);
+            pf_d[2] = at32(disp_b, o1 + (unsigned)tx.i0); pf_d[3] = at32(disp_b, o1 + (unsigned)tx.i1);
         }
     };
     auto prefetch_ssim_row = [&](int sr) {      // identity loss + noise of row sr (PRE: target statistics, best identity)

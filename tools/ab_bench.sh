@@ -14,5 +14,5 @@ PY
 for lib in "$PK"/libmdx_hip.so "$PK"/libmdx_ab_*.so; do
     n=$(basename "$lib" .so)
     run "$n" "$lib"
-    run "${n}_noprologue" "$lib" --no-prologue
+    [ -n "$AB_NOPROLOGUE" ] && run "${n}_noprologue" "$lib" --no-prologue
 done

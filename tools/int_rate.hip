@@ -61,6 +61,87 @@ __global__ __launch_bounds__(256) void k(int *out, int w, int pitch)
 #define X(i) asm volatile("v_dot4_u32_u8 %0, %1, %2, %0" : "+v"(a[i]) : "v"(b[i]), "s"(w));
             R8(X)
 #undef X
+        } else if (MODE == 11) {
+#define X(i) asm volatile("v_rcp_f32 %0, %1" : "=v"(a[i]) : "v"(b[i]));
+            R8(X)
+#undef X
+        } else if (MODE == 12) {
+#define X(i) asm volatile("v_mul_lo_u32 %0, %1, %2" : "=v"(a[i]) : "v"(b[i]), "v"(b[(i + 1) & 7]));
+            R8(X)
+#undef X
+        } else if (MODE == 13) {
+            long long q[8];
+#define X(i) asm volatile("v_lshl_add_u64 %0, %1, 2, %2" : "=v"(q[i]) : "v"((long long)b[i]), "v"((long long)b[(i + 1) & 7]));
+            R8(X)
+#undef X
+            for (int i = 0; i < 8; ++i) a[i] ^= (int)q[i];
+        } else if (MODE == 14) {
+#define X(i) asm volatile("v_add_f32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf" : "=v"(a[i]) : "v"(b[i]), "v"(b[(i + 1) & 7]));
+            R8(X)
+#undef X
+        } else if (MODE == 15) {
+#define X(i) asm volatile("v_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a[i]) : "v"(b[i]));
+            R8(X)
+#undef X
+        } else if (MODE == 16) {
+#define X(i) asm volatile("v_div_scale_f32 %0, vcc, %1, %2, %1" : "=v"(a[i]) : "v"(b[i]), "v"(b[(i + 1) & 7]) : "vcc");
+            R8(X)
+#undef X
+        } else if (MODE == 17) {
+#define X(i) asm volatile("v_div_fixup_f32 %0, %1, %2, %3" : "=v"(a[i]) : "v"(b[i]), "v"(b[(i + 1) & 7]), "v"(b[(i + 2) & 7]));
+            R8(X)
+#undef X
+        } else if (MODE == 18) {
+#define X(i) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(b[i]), "v"(b[(i + 1) & 7]));
+            R8(X)
+#undef X
+        } else if (MODE == 19) {
+#define X(i) asm volatile("v_add_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf" : "=v"(a[i]) : "v"(b[i]), "v"(b[(i + 1) & 7]));
+            R8(X)
+#undef X
+        } else if (MODE == 30) {
+#define X(i) asm volatile("v_cndmask_b32_e32 %0, %1, %2, vcc" : "=v"(a[i]) : "v"(b[i]), "v"(b[(i + 1) & 7]) : "vcc");
+            R8(X)
+#undef X
+        } else if (MODE == 31) {
+            unsigned long long m = 0x5555555555555555ull;
+#define X(i) asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(a[i]) : "v"(b[i]), "v"(b[(i + 1) & 7]), "s"(m));
+            R8(X)
+#undef X
+        } else if (MODE == 32) {
+#define X(i) asm volatile("v_mov_b32 %0, %1" : "=v"(a[i]) : "v"(b[i]));
+            R8(X)
+#undef X
+        } else if (MODE == 33) {
+#define X(i) asm volatile("v_cmp_lt_f32 vcc, %0, %1" :: "v"(b[i]), "v"(b[(i + 1) & 7]) : "vcc");
+            R8(X)
+#undef X
+        } else if (MODE == 34) {
+            unsigned long long m;
+#define X(i) asm volatile("v_cmp_lt_f32_e64 %0, %1, %2" : "=s"(m) : "v"(b[i]), "v"(b[(i + 1) & 7]));
+            R8(X)
+#undef X
+            asm volatile("" :: "s"(m));
+        } else if (MODE == 35) {
+#define X(i) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(a[i]) : "v"(b[i]), "v"(b[(i + 1) & 7]));
+            R8(X)
+#undef X
+        } else if (MODE == 36) {
+#define X(i) asm volatile("v_add_f32 %0, %1, %2" : "=v"(a[i]) : "v"(b[i]), "v"(b[(i + 1) & 7]));
+            R8(X)
+#undef X
+        } else if (MODE == 37) {
+#define X(i) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[i]) : "v"(b[i]), "v"(b[(i + 1) & 7]));
+            R8(X)
+#undef X
+        } else if (MODE == 38) {
+#define X(i) asm volatile("v_cvt_f32_i32 %0, %1" : "=v"(a[i]) : "v"(b[i]));
+            R8(X)
+#undef X
+        } else if (MODE == 39) {
+#define X(i) asm volatile("v_add_u32 %0, %1, %2" : "=v"(a[i]) : "v"(b[i]), "v"(b[(i + 1) & 7]));
+            R8(X)
+#undef X
         } else if (MODE == 20) {
 #define X(i) asm volatile("ds_read_u8 %0, %1 offset:" #i : "=v"(a[i]) : "v"(addr));
             R8(X)
@@ -115,6 +196,12 @@ int main()
     run<0>("v_mad_i32_i24 v, v, s, v", d, 0); run<7>("v_mul_u32_u24 v, v, s", d, 0);
     run<1>("v_mul_i32_i24_sdwa BYTE_1 (sgpr)", d, 0); run<6>("v_mul_i32_i24_sdwa BYTE_1 (vgpr)", d, 0);
     run<2>("v_add3_u32", d, 0); run<3>("v_bfe_u32", d, 0); run<4>("v_and_b32", d, 0); run<5>("v_readlane_b32 (sgpr lane)", d, 0);
+    run<18>("v_fma_f32", d, 0); run<11>("v_rcp_f32", d, 0); run<12>("v_mul_lo_u32", d, 0); run<13>("v_lshl_add_u64", d, 0);
+    run<14>("v_add_f32_dpp row_shr:1", d, 0); run<19>("v_add_f32_dpp wave_shr:1", d, 0); run<15>("v_mov_b32_dpp wave_shr:1", d, 0);
+    run<16>("v_div_scale_f32", d, 0); run<17>("v_div_fixup_f32", d, 0);
+    run<35>("v_mul_f32", d, 0); run<36>("v_add_f32", d, 0); run<37>("v_fmac_f32", d, 0); run<32>("v_mov_b32", d, 0); run<39>("v_add_u32", d, 0);
+    run<30>("v_cndmask_b32_e32 (vcc)", d, 0); run<31>("v_cndmask_b32_e64 (sgpr mask)", d, 0);
+    run<33>("v_cmp_lt_f32 -> vcc", d, 0); run<34>("v_cmp_lt_f32_e64 -> sgpr", d, 0); run<38>("v_cvt_f32_i32", d, 0);
     run<8>("v_alignbyte_b32", d, 0); run<9>("v_perm_b32", d, 0); run<10>("v_dot4_u32_u8", d, 0);
     for (int pitch : {228, 232, 4}) {
         run<20>("ds_read_u8", d, pitch); run<23>("ds_read_u16", d, pitch); run<21>("ds_read_b32", d, pitch); run<22>("ds_read_b64", d, pitch);
