@@ -43,3 +43,22 @@ def test_self_launch_two_ranks_gloo():
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["ranks_verified"] == 2
+
+
+def test_committed_counter_summary_matches_the_sources():
+    """bench.py quotes profiles/r03_bench_kernel_pmc.json (traffic, VALU issue) only for the build it was taken on, recognised by
+    the hash of the kernel sources and flags.  A source change without a new counter pass makes those fields null in the bench
+    line: this test says so (skip, not failure: the numbers' absence is reported by bench.py itself)."""
+    import importlib.util
+    import json
+    import pytest
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "digging-into-self-supervised-monocular-depth-estimation_amd")
+    spec = importlib.util.spec_from_file_location("_mdx_build_t", os.path.join(pkg, "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    pmc = json.load(open(os.path.join(root, "profiles", "r03_bench_kernel_pmc.json")))
+    assert len(b.source_sha16()) == 16
+    if pmc.get("source_sha16") != b.source_sha16():
+        pytest.skip("profiles/r03_bench_kernel_pmc.json was taken on other kernel sources (%s, now %s): run "
+                    "tools/profile_round3.sh on the GPU box and --collect" % (pmc.get("source_sha16"), b.source_sha16()))
