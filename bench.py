@@ -347,7 +347,7 @@ def trainer_loop(args, frame_ids, steps, warmup, workers, raw):
     gc.collect()
     torch.cuda.synchronize()
     return {"value": world * args.batch * steps / dt, "unit": "images/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
-            "n_gpus": world, "gradient_exchange": exchange,
+            "n_gpus": world, "gradient_exchange": exchange, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)"),
             "workers": workers, "uint8_loader": bool(opt.uint8_loader), "hip_graph": graphed,
             "raw_frames": raw, "what": "model_train.trainer: DataLoader (" + ("decoded 1242x375 frames, Lanczos pyramid / jitter / ToTensor on the GPU, " if raw else "prepared uint8 entries, ") + "pinned, side-stream upload) -> train_step -> control.metric every step", "abs_rel_monitor": vals.get("abs_rel")}
 
@@ -360,6 +360,10 @@ def trainer_loop_child(feed, port=None):
     keep = [a for a in sys.argv[1:] if a not in ("--one-loop",)]
     cmd = [sys.executable, os.path.abspath(__file__), "--trainer-loop-child", feed] + keep
     env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
+    if (int(os.environ.get("WORLD_SIZE", "1")) > 1 or "--dist" in keep) and os.environ.get("MDX_HW_QUEUES", "") != "0":
+        # what model_train.py does for a data-parallel run (see there): two hardware queues for the loop's process, so that
+        # the graph's RCCL branch and the prefetcher's stream do not share one; this process (the resident step) keeps the default
+        env.setdefault("GPU_MAX_HW_QUEUES", os.environ.get("MDX_HW_QUEUES") or "2")
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         env["MASTER_PORT"] = str(port)             # a free port rank 0 picked and broadcast to the job
     else:

@@ -6,8 +6,17 @@
 import os
 import sys
 
-import numpy as np
-import torch
+# Data-parallel runs: the step's hipGraph holds the RCCL all-reduce as a second branch, and with the HIP runtime's default of 4
+# hardware queues per device that branch shares a queue with the prefetcher's side stream (uploads + image preparation): the
+# loader-fed loop then runs 1.0-1.3 ms per step behind the same loop on a resident batch (measured with a process group of one
+# rank: fp32 22.65 -> 21.60 ms, bf16 15.34 -> 14.31 ms with 2 queues; 1: 15.5, 3: 14.4, 8: 14.2, 16: 14.7 -- tools/
+# sweep_hw_queues.sh).  The runtime reads the variable when it is loaded, i.e. before `import torch`.  MDX_HW_QUEUES=0 leaves
+# the runtime's default, MDX_HW_QUEUES=n asks for n; a value the user exported (GPU_MAX_HW_QUEUES) is never overridden.
+if os.environ.get("MDX_HW_QUEUES", "") != "0" and (int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("MDX_HW_QUEUES")):
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", os.environ.get("MDX_HW_QUEUES") or "2")
+
+import numpy as np        # noqa: E402
+import torch              # noqa: E402
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from model_option import options      # noqa: E402
