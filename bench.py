@@ -360,7 +360,8 @@ def trainer_loop_child(feed, port=None):
     keep = [a for a in sys.argv[1:] if a not in ("--one-loop",)]
     cmd = [sys.executable, os.path.abspath(__file__), "--trainer-loop-child", feed] + keep
     env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
-    if (int(os.environ.get("WORLD_SIZE", "1")) > 1 or "--dist" in keep) and os.environ.get("MDX_HW_QUEUES", "") != "0":
+    if ((int(os.environ.get("WORLD_SIZE", "1")) > 1 or "--dist" in keep) and "--trainer-eager" not in keep
+            and os.environ.get("MDX_HW_QUEUES", "") != "0"):
         # what model_train.py does for a data-parallel run (see there): two hardware queues for the loop's process, so that
         # the graph's RCCL branch and the prefetcher's stream do not share one; this process (the resident step) keeps the default
         env.setdefault("GPU_MAX_HW_QUEUES", os.environ.get("MDX_HW_QUEUES") or "2")

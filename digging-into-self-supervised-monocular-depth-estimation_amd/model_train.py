@@ -12,7 +12,18 @@ import sys
 # rank: fp32 22.65 -> 21.60 ms, bf16 15.34 -> 14.31 ms with 2 queues; 1: 15.5, 3: 14.4, 8: 14.2, 16: 14.7 -- tools/
 # sweep_hw_queues.sh).  The runtime reads the variable when it is loaded, i.e. before `import torch`.  MDX_HW_QUEUES=0 leaves
 # the runtime's default, MDX_HW_QUEUES=n asks for n; a value the user exported (GPU_MAX_HW_QUEUES) is never overridden.
-if os.environ.get("MDX_HW_QUEUES", "") != "0" and (int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("MDX_HW_QUEUES")):
+# Only for the captured step (--graph, the default): an EAGER data-parallel step is fastest with the runtime's default (1-rank
+# group, resident batch: 576 images/s at 4 queues, 563 at 2, 561 at 8).
+def _graph_requested(argv):
+    for i, a in enumerate(argv):
+        v = a.split("=", 1)[1] if a.startswith("--graph=") else (argv[i + 1] if a == "--graph" and i + 1 < len(argv) else None)
+        if v is not None:
+            return str(v).lower() in ("1", "true", "yes")
+    return True
+
+
+if os.environ.get("MDX_HW_QUEUES", "") != "0" and (os.environ.get("MDX_HW_QUEUES") or
+                                                   (int(os.environ.get("WORLD_SIZE", "1")) > 1 and _graph_requested(sys.argv[1:]))):
     os.environ.setdefault("GPU_MAX_HW_QUEUES", os.environ.get("MDX_HW_QUEUES") or "2")
 
 import numpy as np        # noqa: E402
