@@ -107,3 +107,32 @@ def test_depth_monitor_kernel_vs_reference(G):
     empty = compute_depth_metric({("depth", 0): torch.zeros(1, 1, 375, 1242, device=G.DEV)},
                                  {("depth", 0, 0): torch.ones(1, 1, 192, 640, device=G.DEV)}, "torch")
     assert all(np.isnan(float(v)) for v in empty)
+
+
+def test_depth_monitor_dense_single_and_repeat(G):
+    """the compacting monitor at the ends of its range: every pixel of the window valid (the compact arrays as large as the
+    window, 23 slices per radix block), ONE valid pixel, values that all share their high bits -- against the torch-op form --
+    and twice in a row on one workspace (the radix passes leave their histograms empty): bit-equal results."""
+    from model_loss import compute_depth_metric
+    import model_loss.model_metric as mm
+    g = torch.Generator().manual_seed(11)
+    cases = []
+    dense = 1.0 + 60 * torch.rand(2, 1, 375, 1242, generator=g)
+    cases.append(("dense", dense, torch.rand(2, 1, 192, 640, generator=g) * 50 + 0.5))
+    one = torch.zeros(2, 1, 375, 1242)
+    one[1, 0, 200, 700] = 17.5
+    cases.append(("single", one, torch.rand(2, 1, 192, 640, generator=g) * 50 + 0.5))
+    narrow = torch.zeros(2, 1, 375, 1242)
+    m = torch.rand(2, 1, 375, 1242, generator=g) < 0.1
+    narrow[m] = 10.0 + 1e-3 * torch.rand(int(m.sum()), generator=g)        # one exponent, a few mantissa patterns apart
+    cases.append(("narrow", narrow, 10.0 + 1e-3 * torch.rand(2, 1, 192, 640, generator=g)))
+    keep, mm.METRIC_CAPACITY = mm.METRIC_CAPACITY, 1.0
+    try:
+        for name, gt, pred in cases:
+            ref = np.array([float(v) for v in compute_depth_metric({("depth", 0): gt}, {("depth", 0, 0): pred}, "torch")])
+            a = torch.stack(list(compute_depth_metric({("depth", 0): gt.to(G.DEV)}, {("depth", 0, 0): pred.to(G.DEV)}, "torch")))
+            b = torch.stack(list(compute_depth_metric({("depth", 0): gt.to(G.DEV)}, {("depth", 0, 0): pred.to(G.DEV)}, "torch")))
+            assert torch.equal(a, b), name
+            G.assert_close(a.cpu().numpy(), ref, "depth monitor, %s" % name, rel=2e-5)
+    finally:
+        mm.METRIC_CAPACITY = keep
