@@ -22,8 +22,10 @@ def _graph_requested(argv):
     return True
 
 
-if os.environ.get("MDX_HW_QUEUES", "") != "0" and (os.environ.get("MDX_HW_QUEUES") or
-                                                   (int(os.environ.get("WORLD_SIZE", "1")) > 1 and _graph_requested(sys.argv[1:]))):
+# (only when this file is the program: imported by another one -- bench.py -- the runtime is loaded already and the variable
+# would merely leak into that program's child processes)
+if os.path.basename(sys.argv[0] or "") == "model_train.py" and os.environ.get("MDX_HW_QUEUES", "") != "0" and (
+        os.environ.get("MDX_HW_QUEUES") or (int(os.environ.get("WORLD_SIZE", "1")) > 1 and _graph_requested(sys.argv[1:]))):
     os.environ.setdefault("GPU_MAX_HW_QUEUES", os.environ.get("MDX_HW_QUEUES") or "2")
 
 import numpy as np        # noqa: E402
