@@ -149,6 +149,35 @@ def test_color_jitter_bit_exact(G, IP):
             assert np.array_equal(out[n].view(np.uint32), orc.to_tensor(ref).view(np.uint32)), "image %d" % n
 
 
+def test_color_jitter_odd_sizes_and_empty_chains(G, IP):
+    """image sizes that are not multiples of four (the kernels' pixel-by-pixel tails; a plane that starts at an odd address
+    takes them for the whole image), chains with Contrast first / last, and the empty chain (a plain ToTensor)."""
+    from model_loader.kitti import ColorJitter
+    rng = np.random.default_rng(15)
+    for (h, w) in ((7, 9), (5, 13), (6, 10)):
+        imgs = [_natural(rng, h, w) for _ in range(9)]
+        params, refs = [], []
+        for n, img in enumerate(imgs):
+            if n == 8:
+                p = ([4, 4, 4, 4], 1.0, 1.0, 1.0, 0)                                    # the empty chain
+                ref = img
+            else:
+                j = ColorJitter(random.Random(100 + n))
+                order = list(j.order)
+                if n < 2:
+                    order.remove(1); order.insert(0, 1)                                 # Contrast first
+                elif n < 4:
+                    order.remove(1); order.append(1)                                    # Contrast last
+                p = (order, j.b, j.c, j.s, int(j.h * 255))
+                ref = orc.color_jitter(img, *p)
+            params.append(p)
+            refs.append(ref)
+        src = torch.from_numpy(np.stack([i.transpose(2, 0, 1) for i in imgs])).contiguous().cuda()
+        out = IP.color_jitter(src, params).cpu().numpy()
+        for n, ref in enumerate(refs):
+            assert np.array_equal(out[n].view(np.uint32), orc.to_tensor(ref).view(np.uint32)), ((h, w), n)
+
+
 @pytest.mark.parametrize("hw", [(192, 640), (320, 1024)])
 def test_image_prep_equals_cpu_loader_arithmetic(G, IP, hw):
     """the batch-level stage against what the CPU loader computes per sample with Pillow (model_loader/kitti.py), at
