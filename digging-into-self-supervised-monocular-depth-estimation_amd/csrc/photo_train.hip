@@ -1323,7 +1323,7 @@ struct TrainPlan {
 // tall, the rest in small ones that end the launch without a long ragged tail (a work item is one wave walking
 // rows + 4 steps; their cost also varies with the auto-mask pattern).  In -DMDX_DEV_SWITCHES builds
 // MDX_TRAIN_SCHEDULE="r1,f1,r2,f2,r3" overrides (rows of the levels, fractions of H in levels 1 and 2) for tuning.
-static void choose_levels(const mdx_train_desc *d, TrainPlan &p)
+static void choose_levels(const mdx_train_desc *d, TrainPlan &p, bool grad)
 {
     const int H = d->H;
     int r[3] = {0, 0, 0};
@@ -1341,6 +1341,11 @@ static void choose_levels(const mdx_train_desc *d, TrainPlan &p)
             // 3 x 40 + 2 x 24 + 2 x 12 rows (7 chunks, 220 steps per column) 210.5 us against 223.7 us for round 2's
             // 2 x 40 + 2 x 20 + 8 x 10 (12 chunks, 240 steps); 3 x 40 + 3 x 24 (6 chunks) is unbalanced again (224.6 us)
             r[1] = 24; r[2] = 12; f1 = 0.63; f2 = 0.25;
+            // the forward-only form (validation, torch.no_grad()): two halo rows per chunk instead of four, 4 waves per SIMD
+            // instead of 3, no gradient phase whose cost varies with the mask -- many short chunks balance better than few
+            // tall ones (tools/sweep_schedule_eval.sh on bench.py's batch: 16/8/4 rows 116.5 us, 20/10/5 117.5, 24/12/6
+            // 122.5, the training schedule 127.5, 48/24/12 153)
+            if (!grad) { r[0] = 16; r[1] = 8; r[2] = 4; f1 = 0.6; f2 = 0.3; }
         }
 #ifdef MDX_DEV_SWITCHES      // sweeps of the builder only (MDX_BUILD_DEFINES=-DMDX_DEV_SWITCHES): the shipped library never reads the environment
         if (const char *e = getenv("MDX_TRAIN_SCHEDULE")) {
@@ -1369,10 +1374,10 @@ static void choose_levels(const mdx_train_desc *d, TrainPlan &p)
     p.nchunks = k;
 }
 
-static TrainPlan plan(const mdx_train_desc *d)
+static TrainPlan plan(const mdx_train_desc *d, bool grad)
 {
     TrainPlan p;
-    choose_levels(d, p);
+    choose_levels(d, p, grad);
     p.nstrips = (d->W + SW - 1) / SW;
     p.ncols = d->nscales * d->B * p.nstrips;
     int it = 0;
@@ -1423,7 +1428,9 @@ MDX_EXPORT int mdx_train_desc_init(mdx_train_desc *d, int B, int H, int W, int S
 
 MDX_EXPORT size_t mdx_photometric_train_workspace_bytes(const mdx_train_desc *d)
 {
-    return validate_train(d) ? 0 : plan(d).total;
+    if (validate_train(d)) return 0;
+    const size_t a = plan(d, true).total, b = plan(d, false).total;      // one workspace serves both forms of the launch
+    return a > b ? a : b;
 }
 
 struct PreInputs {                      // what photo_prologue.hip wrote for this step (all null: ident / noise form)
@@ -1452,7 +1459,7 @@ static int train_launch(const mdx_train_desc *d, const float *const *disp, const
     } else if (automask && (!ident || !noise)) return MDX_ERR_NULL_POINTER;
     for (int f = 0; f < d->S; ++f)
         if (!src->img[f]) return MDX_ERR_NULL_POINTER;
-    const TrainPlan p = plan(d);
+    const TrainPlan p = plan(d, grad);
     if (!workspace || workspace_bytes < p.total) return MDX_ERR_WORKSPACE;
     if (!aligned(workspace, 16)) return MDX_ERR_MISALIGNED;
     if (p.items >= (1ull << 31)) return MDX_ERR_BAD_SHAPE;
