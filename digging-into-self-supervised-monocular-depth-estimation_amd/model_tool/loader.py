@@ -128,13 +128,14 @@ class setting(object):
             # one flat gradient buffer + bucketed all-reduce(mean) issued from inside backward (model_tool/parallel.py):
             # capturable together with the rest of the step; buffers (batch-norm statistics) stay per GPU as in the
             # single-device reference, parameters start from rank 0's
-            from .parallel import grad_sync, broadcast_state
+            from .parallel import grad_sync, broadcast_state, dp_graph_allowed
             broadcast_state(self.model.values())
             comm = {"fp32": None, "bf16": torch.bfloat16}[str(_opt(opt, "grad_comm", "fp32"))]
             # a captured step exchanges ONE bucket when backward ends; an eager one overlaps 32 MB buckets with backward
             # (measured: model_tool/parallel.py)
             captured = bool(_opt(opt, "graph", False)) and str(self.device).startswith("cuda") \
-                and str(_opt(opt, "noise", "device")) != "cpu" and torch.distributed.get_backend() == "nccl"
+                and str(_opt(opt, "noise", "device")) != "cpu" and torch.distributed.get_backend() == "nccl" \
+                and dp_graph_allowed(torch.distributed.get_world_size())       # = trainer.can_graph()
             mb = int(_opt(opt, "bucket_mb", 0)) or ((1 << 20) if captured else 32)
             self.sync = grad_sync(self.parameters, bucket_mb=mb, comm_dtype=comm)
 

@@ -70,7 +70,7 @@ class control(object):
                 print("  {} {:0.3f}".format(key, self._mean(v) if isinstance(v, (list, tuple)) else float(v)), end=" ")
             print(" ")
 
-    def save(self, epoch, train_log, valid_log, setting):
+    def save(self, epoch, train_log, valid_log, setting, compute=None):
         if int(os.environ.get("RANK", "0")) != 0:
             return
         save_directory = os.path.join("./model_save", self.opt.save)
@@ -83,6 +83,9 @@ class control(object):
             # what a restart needs beyond the reference's files (it saves weights only, logger.py:51-68)
             torch.save({"epoch": epoch + 1, "optimizer": setting.optim["optimizer"].state_dict(),
                         "scheduler": setting.optim["scheduler"].state_dict(),
+                        # steps served by the in-kernel noise generator (compute.noise_rng): a resumed run goes on in the
+                        # stream instead of replaying the draws of epoch 0
+                        "noise_offset": compute.noise_offset() if compute is not None else None,
                         "train_log": {k: list(v) for k, v in train_log.items()},
                         "valid_log": {k: list(v) for k, v in valid_log.items()}},
                        os.path.join(save_directory, "state" + str(epoch + 1) + ".pt"))
@@ -91,7 +94,7 @@ class control(object):
                 np.save(os.path.join(loss_directory, key + ".npy"), np.asarray(valid_log[key]))
                 np.save(os.path.join(loss_directory, "train_" + key + ".npy"), np.asarray(train_log[key]))
 
-    def resume(self, setting, epoch, train_log=None, valid_log=None):
+    def resume(self, setting, epoch, train_log=None, valid_log=None, compute=None):
         """Restart from the files `save` wrote after `epoch` epochs (every rank loads them): network weights from the
         reference-named `<key><epoch>.pt`, optimiser, scheduler and the per-epoch logs so far (so that the loss/*.npy
         files of the finished run cover every epoch) from `state<epoch>.pt`.  `epoch` must be one `save` wrote a
@@ -107,6 +110,8 @@ class control(object):
         state = torch.load(os.path.join(save_directory, "state" + str(epoch) + ".pt"), map_location=self.device)
         setting.optim["optimizer"].load_state_dict(state["optimizer"])
         setting.optim["scheduler"].load_state_dict(state["scheduler"])
+        if compute is not None and state.get("noise_offset") is not None:
+            compute.set_noise_offset(state["noise_offset"])
         for mine, key in ((train_log, "train_log"), (valid_log, "valid_log")):
             if mine is not None and key in state:
                 for k in mine:

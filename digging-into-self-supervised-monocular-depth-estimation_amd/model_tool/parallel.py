@@ -28,9 +28,57 @@ step uses ONE bucket, issued when backward ends (`setting` picks bucket_mb accor
 
 xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce of the 107 MB (ResNet-18 depth + pose, fp32) is
 link-bound at ~0.5-1 ms against a >=13 ms step.  `comm_dtype=torch.bfloat16` halves the bytes (gradients are rounded
-once before the sum; off by default)."""
+once before the sum; off by default).
+
+Collectives and stream capture (the round-3 core dump): a collective issued SYNCHRONOUSLY (async_op=False)
+inside `torch.cuda.graph` registers its work with ProcessGroupNCCL's watchdog thread, which then polls an event that was
+recorded in the capturing stream -- hipErrorCapturedEvent, std::terminate, the whole rank gone.  Only an `async_op=True`
+collective whose wait() is a stream-side wait (what grad_sync issues) may be captured.  Every other collective of this
+module refuses to run while the current stream is capturing (`_refuse_under_capture`): a RuntimeError in the caller
+instead of an abort in another thread.
+
+Contract of grad_sync: exactly ONE backward between zero() and finish().  A second one (gradient accumulation,
+retain_graph) would add local gradients into the already exchanged views; the hook raises instead."""
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def dp_graph_allowed(world):
+    """May the step of a `world`-rank job be captured into a hipGraph (exchange included)?  One rank: yes (measured and
+    tested on the GPU: tests/test_gpu_driver.py).  Several ranks: only with MDX_DP_GRAPH=1 -- a captured MULTI-rank RCCL
+    all-reduce (fork / join of the communicator's stream inside the capture, replay order across ranks) has not run on
+    hardware yet (no multi-GPU node was available to this build: SCALE_r01..r03 were skipped), so the default
+    data-parallel step is the eager one with 32 MB buckets overlapping backward.  tools/scale_check.sh holds the runs
+    that settle it."""
+    return int(world) <= 1 or os.environ.get("MDX_DP_GRAPH", "") == "1"
+
+
+def capturing():
+    """True while the current HIP stream is being captured into a graph."""
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+
+def _refuse_under_capture(what):
+    if capturing():
+        raise RuntimeError(
+            "%s is a synchronous collective and the current stream is being captured into a hipGraph: the process "
+            "group's watchdog would query an event recorded inside the capture (hipErrorCapturedEvent) and abort the "
+            "rank.  Call it outside torch.cuda.graph(); only grad_sync's asynchronous all-reduce is capturable." % what)
+
+
+def grad_view(flat, offset, p):
+    """The slice of the flat buffer that serves as `p.grad`: same shape AND strides as the parameter (a channels_last
+    weight gets a channels_last gradient -- torch's fused Adam requires params, grads and moments to share one layout and
+    pairs elements by storage order otherwise)."""
+    expect = 1
+    for st, sz in sorted((st, sz) for st, sz in zip(p.stride(), p.shape) if sz != 1):
+        if st != expect:                         # non-overlapping and dense: a permutation of the contiguous strides
+            raise ValueError("grad_sync: parameter of shape %s has strides %s (not dense)" % (tuple(p.shape), p.stride()))
+        expect *= sz
+    # the parameter's strides verbatim, size-1 dimensions included: the fused optimiser compares stride tuples
+    return flat.as_strided(p.shape, p.stride(), storage_offset=offset)
 
 
 def _align(n, a=64):
@@ -70,8 +118,7 @@ class grad_sync(object):
         for k, (_, _, members) in enumerate(self.buckets):
             for p in members:
                 self._bucket_of[id(p)] = k
-                o = self.offsets[id(p)]
-                self._views[id(p)] = self.flat[o:o + p.numel()].view_as(p)
+                self._views[id(p)] = grad_view(self.flat, self.offsets[id(p)], p)
         self._avg = self.backend == "nccl"                      # ncclAvg exists in RCCL; gloo only sums
         self._works = []
         self._reset()
@@ -91,6 +138,11 @@ class grad_sync(object):
 
     def _ready(self, p):
         k = self._bucket_of[id(p)]
+        if k < self._next:
+            # the bucket is on the wire (or back) and `.grad` is the exchanged view: this gradient comes from a SECOND
+            # backward since zero() and was accumulated, rank-locally, into the reduced values
+            raise RuntimeError("grad_sync: a gradient arrived after its bucket was exchanged -- more than one backward "
+                               "between zero() and finish() (gradient accumulation / retain_graph are not supported)")
         self._pending[k] -= 1
         while self._next < len(self.buckets) and self._pending[self._next] <= 0:
             self._issue(self._next)
@@ -118,7 +170,10 @@ class grad_sync(object):
         if self.no_comm:
             return
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
-        self._works.append((k, dist.all_reduce(buf, op=op, group=self.group, async_op=True)))
+        # async_op=True is what makes this capturable (module docstring): never change it to a blocking call
+        work = dist.all_reduce(buf, op=op, group=self.group, async_op=True)
+        assert work is not None, "grad_sync: the all-reduce must be asynchronous"
+        self._works.append((k, work))
 
     def finish(self):
         """After backward: every bucket exchanged and visible to the current stream (no host synchronisation on GPU)."""
@@ -143,6 +198,7 @@ class grad_sync(object):
 
 def broadcast_state(modules, src=0, group=None):
     """Every rank starts from rank `src`'s parameters and buffers (what DDP's constructor does)."""
+    _refuse_under_capture("broadcast_state")
     with torch.no_grad():
         for m in modules:
             for t in list(m.parameters()) + list(m.buffers()):
@@ -151,6 +207,8 @@ def broadcast_state(modules, src=0, group=None):
 
 def mean_over_ranks(values, device, group=None):
     """Scalars (one per metric) averaged over the job: one all-reduce of len(values) numbers."""
+    if dist.is_available() and dist.is_initialized():
+        _refuse_under_capture("mean_over_ranks")          # (also with one rank: float() below would synchronise the capture)
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return [float(v) for v in values]
     dev = device if dist.get_backend(group) == "nccl" else "cpu"

@@ -223,6 +223,31 @@ class compute(object):
         return inputs, outputs
 
     # -- loss -------------------------------------------------------------------------------------
+    def draws_in_kernel(self):
+        """Does the step draw its auto-mask noise inside the prologue kernel (device {seed, offset} state)?"""
+        return (self.fused and self.fused_train and self.prologue and bool(self.opt.use_automasking)
+                and self.noise_mode != "cpu" and len(self.opt.scales) <= 4)
+
+    def noise_rng(self, device=None):
+        """The device-resident {seed, offset} of the in-kernel generator (created at first use; the offset counts the
+        steps taken: the finishing kernel of every step advances it).  Part of the run's state: control.save stores the
+        offset, control.resume puts it back (set_noise_offset), graphed_step's warm-up restores it."""
+        if self._rng is None:
+            import os
+            self._rng = F.noise_state(device or self.device, stream=int(_opt(self.opt, "noise_stream", os.environ.get("RANK", "0"))))
+            if getattr(self, "_rng_offset0", None) is not None:
+                self._rng.tensor[1] = int(self._rng_offset0)
+        return self._rng
+
+    def noise_offset(self):
+        """Steps the in-kernel generator has served (None: it has not been used)."""
+        return None if self._rng is None else int(self._rng.tensor[1])
+
+    def set_noise_offset(self, value):
+        self._rng_offset0 = None if value is None else int(value)
+        if self._rng is not None and value is not None:
+            self._rng.tensor[1] = int(value)
+
     def _noise(self, shape):
         if self.noise_mode == "cpu":
             return torch.randn(shape).to(self.device)
@@ -254,9 +279,8 @@ class compute(object):
                     noises = [inputs[("noise", s)] for s in opt.scales]
                 elif self.noise_mode == "cpu":
                     noises = list(self._noise((nsc, B, S, H, W)).unbind(0))
-                elif self.prologue and self._rng is None:
-                    import os
-                    self._rng = F.noise_state(target.device, stream=int(_opt(opt, "noise_stream", os.environ.get("RANK", "0"))))
+                elif self.prologue:
+                    self.noise_rng(target.device)
             pre = None
             if self.prologue:
                 pre = F.photometric_prologue(target, sources, nsc, noises=noises, rng=self._rng, automask=automask)

@@ -12,8 +12,10 @@ import sys
 # rank: fp32 22.65 -> 21.60 ms, bf16 15.34 -> 14.31 ms with 2 queues; 1: 15.5, 3: 14.4, 8: 14.2, 16: 14.7 -- tools/
 # sweep_hw_queues.sh).  The runtime reads the variable when it is loaded, i.e. before `import torch`.  MDX_HW_QUEUES=0 leaves
 # the runtime's default, MDX_HW_QUEUES=n asks for n; a value the user exported (GPU_MAX_HW_QUEUES) is never overridden.
-# Only for the captured step (--graph, the default): an EAGER data-parallel step is fastest with the runtime's default (1-rank
-# group, resident batch: 576 images/s at 4 queues, 563 at 2, 561 at 8).
+# Only for the captured step: an EAGER data-parallel step is fastest with the runtime's default (1-rank group, resident batch:
+# 576 images/s at 4 queues, 563 at 2, 561 at 8).  With WORLD_SIZE > 1 the step is captured only when MDX_DP_GRAPH=1 asks for
+# it (model_tool/parallel.py: dp_graph_allowed -- a captured multi-rank exchange has not run on hardware yet), so the queue
+# count follows that switch too.
 def _graph_requested(argv):
     for i, a in enumerate(argv):
         v = a.split("=", 1)[1] if a.startswith("--graph=") else (argv[i + 1] if a == "--graph" and i + 1 < len(argv) else None)
@@ -25,7 +27,8 @@ def _graph_requested(argv):
 # (only when this file is the program: imported by another one -- bench.py -- the runtime is loaded already and the variable
 # would merely leak into that program's child processes)
 if os.path.basename(sys.argv[0] or "") == "model_train.py" and os.environ.get("MDX_HW_QUEUES", "") != "0" and (
-        os.environ.get("MDX_HW_QUEUES") or (int(os.environ.get("WORLD_SIZE", "1")) > 1 and _graph_requested(sys.argv[1:]))):
+        os.environ.get("MDX_HW_QUEUES") or (int(os.environ.get("WORLD_SIZE", "1")) > 1 and _graph_requested(sys.argv[1:])
+                                            and os.environ.get("MDX_DP_GRAPH", "") == "1")):
     os.environ.setdefault("GPU_MAX_HW_QUEUES", os.environ.get("MDX_HW_QUEUES") or "2")
 
 import numpy as np        # noqa: E402
@@ -80,8 +83,9 @@ class graphed_step(object):
     tensor the captured Adam reads).
 
     The warm-up steps capture needs (MIOpen picks its kernels, the allocator settles, RCCL opens its communicator) are
-    side-effect free: weights, batch-norm statistics, Adam moments and step counters are put back afterwards, so the
-    first replay is step 1 of the run -- graph on and graph off follow the same trajectory."""
+    side-effect free: weights, batch-norm statistics, Adam moments, step counters and the offset of the in-kernel noise
+    generator are put back afterwards, so the first replay is step 1 of the run -- graph on and graph off follow the same
+    trajectory and draw the same noise."""
 
     def __init__(self, tr, example, warmup=3):
         self.tr = tr
@@ -102,6 +106,9 @@ class graphed_step(object):
         tensors = [t for net in nets for t in list(net.parameters()) + list(net.buffers())]
         saved = [t.detach().clone() for t in tensors]
         saved_bn = [m._pending_batches for m in self.bns]
+        # the in-kernel noise generator's {seed, offset}: every warm-up step advances the offset on the device
+        rng = tr.compute.noise_rng(dev) if tr.compute.draws_in_kernel() else None
+        saved_rng = rng.tensor.clone() if rng is not None else None
         had_state = {id(p): {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in st.items()}
                      for p, st in opt.state.items()}
         # ONE side stream for the warm-up and the capture: the gradient-accumulation nodes autograd creates during
@@ -122,6 +129,8 @@ class graphed_step(object):
                                 v.copy_(old[k])
                             else:
                                 v.zero_()          # Adam's initial state: zero moments, step 0
+                if rng is not None:
+                    rng.tensor.copy_(saved_rng)
             for m, n in zip(self.bns, saved_bn):
                 m._pending_batches = n
         torch.cuda.current_stream(dev).wait_stream(self.stream)
@@ -218,10 +227,12 @@ class trainer(object):
 
     def can_graph(self):
         """The step is capturable when nothing in it runs on the host: not with the reference's host-side noise
-        (--noise cpu: torch.randn on the CPU + a copy from pageable memory), not with a non-RCCL process group."""
+        (--noise cpu: torch.randn on the CPU + a copy from pageable memory), not with a non-RCCL process group -- and,
+        with more than one rank, only on request (MDX_DP_GRAPH=1; model_tool/parallel.py: dp_graph_allowed)."""
+        from model_tool.parallel import dp_graph_allowed
         sync = self.setting.sync
         return (str(self.device).startswith("cuda") and self.compute.noise_mode != "cpu"
-                and (sync is None or sync.backend == "nccl"))
+                and (sync is None or (sync.backend == "nccl" and dp_graph_allowed(sync.world))))
 
     def train_step(self, inputs):
         """opt.graph (GPU): the step -- under torch.distributed including the gradient exchange -- is captured once
@@ -243,7 +254,7 @@ class trainer(object):
         epoch_valid = {k: [] for k in names}
         start = 0
         if getattr(self.opt, "resume", 0):     # weights, optimiser, scheduler and the per-epoch logs so far
-            start = self.control.resume(self.setting, self.opt.resume, epoch_train, epoch_valid)
+            start = self.control.resume(self.setting, self.opt.resume, epoch_train, epoch_valid, compute=self.compute)
         for epoch in range(start, self.opt.epoch):
             batch_train = {k: [] for k in names}
             batch_valid = {k: [] for k in names}
@@ -276,7 +287,7 @@ class trainer(object):
                 epoch_valid[key].append(mean_valid[key])
             if self.rank == 0:
                 self.control.print(epoch, mean_train, mean_valid)
-            self.control.save(epoch, epoch_train, epoch_valid, self.setting)
+            self.control.save(epoch, epoch_train, epoch_valid, self.setting, compute=self.compute)
 
 
 if __name__ == "__main__":

@@ -28,7 +28,8 @@ def main():
                               disp_smoothness=1e-3, use_automasking=True, pose_type="separate", pose_frames="pair",
                               num_layers=18, weight_init=False, learning_rate=1e-4, scheduler_step=15, epoch=1,
                               save="t", num_workers=0, synthetic_length=8, fused=True, noise="device", amp="none",
-                              bucket_mb=int(os.environ.get("MDX_TEST_BUCKET_MB", "8")), grad_comm=os.environ.get("MDX_TEST_GRAD_COMM", "fp32"))
+                              bucket_mb=int(os.environ.get("MDX_TEST_BUCKET_MB", "8")), grad_comm=os.environ.get("MDX_TEST_GRAD_COMM", "fp32"),
+                              channels_last=os.environ.get("MDX_TEST_CHANNELS_LAST", "0") == "1")
     torch.manual_seed(7)                      # identical initial weights on every rank
     st = setting(o, "cpu")
     cp = compute(o, "cpu")
@@ -37,6 +38,12 @@ def main():
     n_train = sum(p.numel() for m in st.raw_model.values() for p in m.parameters() if p.requires_grad)
     assert sum(p.numel() for p in st.sync.params) == n_train
     assert all(p.grad is None for p in st.sync.params)
+    # the view that will serve as a parameter's gradient has the parameter's own layout (--channels_last: torch's fused Adam
+    # pairs params, grads and moments by storage order and refuses / mispairs mixed layouts)
+    assert all(st.sync._views[id(p)].stride() == p.stride() and st.sync._views[id(p)].shape == p.shape for p in st.sync.params)
+    if o.channels_last:
+        assert any(p.dim() == 4 and not p.is_contiguous() and p.is_contiguous(memory_format=torch.channels_last)
+                   for p in st.sync.params), "no channels_last weight in the model: the case tests nothing"
     # parameters start from rank 0's even when the ranks were seeded differently
     torch.manual_seed(100 + rank)
     probe = setting(o, "cpu")
@@ -112,8 +119,39 @@ def main():
     run(st.model).backward()
     st.sync.finish()
     assert check_grads() < tol
-    # 3. after the step every rank holds the same parameters
+    # the one-backward contract: a second backward before finish() would accumulate local gradients into views that are
+    # already exchanged -- the hook raises instead of letting the optimiser step on reduced + unreduced values
+    st.sync.zero()
+    run(st.model).backward()
+    small = sum((p * p).sum() for p in st.raw_model["pose_decoder"].parameters())
+    try:
+        small.backward()
+        raised = False
+    except RuntimeError as e:
+        raised = "more than one backward" in str(e)
+    assert raised, "a second backward between zero() and finish() went unnoticed"
+    st.sync.finish()                       # drain what the first backward issued
+    st.sync.zero()
+    run(st.model).backward()
+    st.sync.finish()
+    assert check_grads() < tol
+    # 3. after the step every rank holds the same parameters, and they are the single-process Adam step on the mean gradient
+    #    (element pairing by layout: with --channels_last a contiguous gradient view would pair the wrong elements)
+    ref_opt = torch.optim.Adam([p for m in local.values() for p in m.parameters() if p.requires_grad], float(o.learning_rate))
+    for key in local:
+        for p in local[key].parameters():
+            if p.requires_grad:
+                dist.all_reduce(p.grad)
+                p.grad /= world
+    ref_opt.step()
     st.optim["optimizer"].step()
+    for key in st.raw_model:
+        for p1, p2 in zip(st.raw_model[key].parameters(), local[key].parameters()):
+            if p1.requires_grad:
+                # Adam normalises: where the gradients agree to `tol` relative to their maximum, entries near zero may still
+                # take another sign of step; bound by the step size
+                assert float((p1 - p2).abs().max()) <= 2.0 * float(o.learning_rate) + 1e-12
+                assert float((p1 - p2).abs().mean()) <= (1e-3 if o.grad_comm == "fp32" else 0.2) * float(o.learning_rate)
     for key in st.raw_model:
         for p in st.raw_model[key].parameters():
             lo, hi = p.detach().clone(), p.detach().clone()

@@ -251,3 +251,48 @@ def test_abi_reports_misuse_on_gpu(G):
     rc = _lib.lib().mdx_identity_loss(C.byref(d), C.c_void_p(mis.data_ptr()), C.byref(src), _lib.ptr(out), _lib.stream())
     assert rc == -6   # MDX_ERR_MISALIGNED
 
+
+
+@pytest.mark.parametrize("saturate", [False, True])
+def test_ssim_module_backward_vs_autograd(G, saturate):
+    """model_loss.SSIM alone is differentiable (mdx_ssim_bwd): gradients wrt BOTH images for a random per-channel upstream
+    against autograd of the reference formula (model_loss.py:28-41) evaluated in float64 -- no 0.85/3 factor, no L1 term.
+    saturate: y = 1 - x over smooth fields drives (1 - SSIM)/2 to the clamp's upper end over whole regions (gradient
+    exactly zero there), and x = y regions sit on its lower end."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import torch_composite as tc
+    from scipy.ndimage import gaussian_filter
+    rng = np.random.RandomState(5 + int(saturate))
+    B, Cc, H, W = 2, 3, 48, 80
+    base = gaussian_filter(rng.randn(B, Cc, H, W), (0, 0, 3, 3))
+    base = (base - base.min()) / (base.max() - base.min())
+    x = (0.1 + 0.8 * base + 0.02 * rng.randn(B, Cc, H, W)).clip(0, 1).astype(np.float32)
+    if saturate:
+        y = (1.0 - x).astype(np.float32)
+        y[:, :, :, : W // 3] = x[:, :, :, : W // 3]          # identical images: raw = 0, the closed lower end
+    else:
+        y = (0.1 + 0.8 * np.roll(base, 2, axis=3) + 0.02 * rng.randn(B, Cc, H, W)).clip(0, 1).astype(np.float32)
+    up = rng.randn(B, Cc, H, W).astype(np.float32)
+    xt, yt = G.t(x).requires_grad_(True), G.t(y).requires_grad_(True)
+    out = G.F.ssim(xt, yt)
+    out.backward(G.t(up))
+    xr = torch.from_numpy(x).double().requires_grad_(True)
+    yr = torch.from_numpy(y).double().requires_grad_(True)
+    ref = tc.ssim(xr, yr)
+    ref.backward(torch.from_numpy(up).double())
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), atol=2e-5)
+    if saturate:
+        sat = (ref.detach() >= 1.0).float().mean()
+        assert float(sat) > 0.2, "the case does not saturate the clamp (%.3f)" % float(sat)
+    # pixels whose float32 value sits within rounding of a clamp end may take the other branch than float64: compare away
+    # from the ends' float32 neighbourhood by masking the (dilated) set of windows that are that close
+    raw = ref.detach().numpy()
+    near = (np.abs(raw - 1.0) < 1e-5) & (raw < 1.0) | ((raw > 0.0) & (raw < 1e-5))
+    assert near.mean() < 0.01
+    from scipy.ndimage import binary_dilation
+    ok = ~binary_dilation(near, structure=np.ones((1, 1, 5, 5), bool))
+    for name, g, r in (("x", xt.grad, xr.grad), ("y", yt.grad, yr.grad)):
+        g, r = g.cpu().numpy().astype(np.float64), r.numpy()
+        err = np.abs(g - r)[ok].max() / (np.abs(r).max() + 1e-30)
+        assert err <= 1e-4, "d ssim / d %s: rel err %g" % (name, err)

@@ -77,7 +77,10 @@ def _synth_images(B, H, W, S, seed):
     return out, K, invK, Ts, rng
 
 
-def _oracle_case(G, B, H, W, S, seed, nscales=4, automask=True, grads=True, rows=0, white_noise=False, grad_rel=1e-4):
+def _oracle_case(G, B, H, W, S, seed, nscales=4, automask=True, grads=True, rows=0, white_noise=False, grad_rel=1e-4,
+                 pre=False):
+    """pre=True: the step's own path -- mdx_photometric_prologue (injected noise) feeds mdx_photometric_train_pre, i.e. the
+    <S, grad, PRE> instantiation bench.py times -- instead of the ident + noise form."""
     from oracle import oracle as orc
     colors, K, invK, Ts, rng = (_synth if white_noise else _synth_images)(B, H, W, S, seed=seed)
     hw = [(H >> s, W >> s) if H % 8 == 0 and W % 8 == 0 else (H, W) for s in range(nscales)]
@@ -85,12 +88,18 @@ def _oracle_case(G, B, H, W, S, seed, nscales=4, automask=True, grads=True, rows
     noises_np = [rng.randn(B, S, H, W).astype(np.float32) for _ in range(nscales)] if automask else None
     P_ref = np.stack([orc.compose_projection(K, T) for T in Ts])
     srcs = [G.t(x) for x in colors[1:]]
-    ident = G.F.identity_loss(G.t(colors[0]), srcs) if automask else None
     disps = [G.t(x).requires_grad_(True) for x in disps_np]
     Pt = G.t(P_ref).requires_grad_(True)
-    out = G.F.photometric_train(disps, Pt, G.t(colors[0]), srcs, G.t(invK), ident,
-                                [G.t(x) for x in noises_np] if automask else None, automask=automask,
-                                need_depth=True, need_to_opt=True, rows_per_chunk=rows)
+    if pre:
+        prologue = G.F.photometric_prologue(G.t(colors[0]), srcs, nscales, automask=automask,
+                                            noises=[G.t(x) for x in noises_np] if automask else None)
+        out = G.F.photometric_train(disps, Pt, G.t(colors[0]), srcs, G.t(invK), automask=automask, need_depth=True,
+                                    need_to_opt=True, rows_per_chunk=rows, pre=prologue)
+    else:
+        ident = G.F.identity_loss(G.t(colors[0]), srcs) if automask else None
+        out = G.F.photometric_train(disps, Pt, G.t(colors[0]), srcs, G.t(invK), ident,
+                                    [G.t(x) for x in noises_np] if automask else None, automask=automask,
+                                    need_depth=True, need_to_opt=True, rows_per_chunk=rows)
     n = B * H * W
     (out["sums"].sum() / n).backward()
     gP_ref = 0
@@ -128,6 +137,17 @@ def test_train_kernel_vs_oracle_batch12(G):
     """configs[1] as bench.py runs it (12 x 192 x 640, S = 2, all four scales): indices, to_optimise, sums AND the
     gradients -- d(P) is then the fixed-order sum over the 12 images' work items (train_finish_kernel)."""
     _oracle_case(G, 12, 192, 640, 2, seed=77, nscales=4, grads=True)
+
+
+@pytest.mark.parametrize("B,H,W,S,nscales", [
+    (12, 192, 640, 2, 4),      # configs[1]: <2, grad, PRE> at the bench's batch -- the prologue and train_finish_kernel's fixed-order
+                               # d(P) sum over 12 images' items, looked at together, against the oracle directly
+    (2, 192, 640, 3, 4),       # configs[4]: <3, grad, PRE>
+    (1, 320, 1024, 2, 4),      # configs[3]'s resolution (its own chunk schedule)
+    (1, 100, 150, 2, 1),       # ragged
+])
+def test_train_kernel_with_prologue_vs_oracle(G, B, H, W, S, nscales):
+    _oracle_case(G, B, H, W, S, seed=177 + S, nscales=nscales, grads=True, pre=True)
 
 
 def test_train_kernel_vs_oracle_white_noise(G):

@@ -1,13 +1,13 @@
 #!/bin/bash
 # PMC + kernel-trace passes over bench.py ITSELF: the counters of the photometric kernels are taken on the launches
 # (and tensors) of the very step bench.py times -- VERDICT r2 weak #2: round 2's counters came from tools/kbench.py's data.
-#   gpurun --timeout 1100 -- 'bash tools/pmc_bench.sh [extra bench.py args]'
+#   gpurun --timeout 1100 -- '[PMC_OUT=dir PMC_SHAPE="B=.., HxW, S=.."] bash tools/pmc_bench.sh [extra bench.py args]'
 #   python tools/pmc_to_json.py gpurun_out/pmc_bench profiles/r03_bench_kernel_pmc.json 12 192 640 2 4
 # rocprofv3 rules on this pool: program directly after `--`, counters in their own passes (only --kernel-trace beside
 # --pmc), cwd /tmp.  --kernel-include-regex keeps the serialising counter collection off the ~1600 other launches of a step.
 set -o pipefail
 ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
-OUT="$ROOT/gpurun_out/pmc_bench"
+OUT="$ROOT/gpurun_out/${PMC_OUT:-pmc_bench}"
 rm -rf "$OUT"; mkdir -p "$OUT" && cd /tmp && export TMPDIR=/tmp
 BENCH="$ROOT/bench.py --no-cpu-baseline --no-trainer-loop --no-roofline"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 $BENCH --steps 30 --warmup 10 "$@" > "$OUT/trace.log" 2>&1
@@ -23,5 +23,10 @@ for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" \
         --output-format csv -d "$OUT/pmc_$i" -- python3 $BENCH --steps 6 --warmup 4 "$@" > "$OUT/pmc_$i.log" 2>&1
     echo "pmc pass $i ($grp): rc=$?"
 done
-MDX_PMC_TITLE="python bench.py $*: the timed step's own launches; B=12, 192x640, S=2, four scales" MDX_PMC_FILTER="mdx::photometric,mdx::train_finish,mdx::smooth" python3 "$ROOT/tools/pmc_summary.py" "$OUT/summary.txt" "$OUT"/pmc_* > /dev/null
+# gpurun merges at most 64 MiB back: of every pass's kernel trace keep the hand-written kernels' rows (the --stats summary of the
+# trace pass, which covers every kernel of the step, is small and stays)
+find "$OUT" -name '*_kernel_trace.csv' | while read -r f; do { head -1 "$f"; grep 'mdx::' "$f"; } > "$f.tmp"; mv "$f.tmp" "$f"; done
+find "$OUT" \( -name '*.db' -o -name '*.pftrace' -o -name '*.json' \) -size +1M -delete
+du -sh "$OUT" | sed 's/^/kept: /'
+MDX_PMC_TITLE="python bench.py $*: the timed step's own launches; ${PMC_SHAPE:-B=12, 192x640, S=2}, four scales" MDX_PMC_FILTER="mdx::photometric,mdx::train_finish,mdx::smooth" python3 "$ROOT/tools/pmc_summary.py" "$OUT/summary.txt" "$OUT"/pmc_* > /dev/null
 cat "$OUT/summary.txt"
