@@ -174,7 +174,8 @@ def cpu_baseline(batch=4, steps=10):
     return out
 
 
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_bench_kernel_pmc.json")   # written by tools/pmc_bench.sh
+# written by tools/pmc_bench.sh + tools/pmc_to_json.py: one file per BASELINE workload shape (configs[1], [4], [3])
+PMC_FILES = [os.path.join(ROOT, "profiles", n) for n in ("r04_bench_kernel_pmc.json", "r04_pmc_c4.json", "r04_pmc_c3.json")]
 
 
 def roofline_blocks(args, opt, frame_ids, tsum):
@@ -206,7 +207,8 @@ def roofline_blocks(args, opt, frame_ids, tsum):
     traffic = issue = None
     try:
         import hashlib
-        pmc = json.load(open(PMC_FILE))
+        want = [args.batch, opt.height, opt.width, nS, nsc]
+        pmc = next(d for d in (json.load(open(f)) for f in PMC_FILES if os.path.exists(f)) if d.get("shape") == want)
         from mdx import LIB_PATH
         so = hashlib.sha256(open(LIB_PATH, "rb").read()).hexdigest()[:16]
         import importlib.util
@@ -220,23 +222,23 @@ def roofline_blocks(args, opt, frame_ids, tsum):
         same_shape = pmc.get("shape") == [args.batch, opt.height, opt.width, nS, nsc]
         if ent and same_shape and same_build:
             traffic = ent.get("traffic_bytes")
-            issue = {kk: ent[kk] for kk in ("valu_wave_insts", "valu_issue_us", "valu_busy_us", "wait_any_frac",
+            issue = {kk: ent[kk] for kk in ("valu_wave_insts", "valu_busy_us", "wait_any_frac",
                                             "wait_inst_frac", "active_frac", "kernel_us_profiled") if kk in ent}
             issue["source"] = pmc.get("source")
-    except (OSError, ValueError, KeyError):
+    except (OSError, ValueError, KeyError, StopIteration):
         pass
     launch_us = 1e3 * k[dom]["ms"]
-    # VALU-issue roofline of the same launch: wave-instructions x 2 cycles / (1024 SIMDs x 2.4 GHz) over its duration
-    valu_frac = (issue["valu_issue_us"] / launch_us) if issue and issue.get("valu_issue_us") else None
     # share of the launch during which the SIMDs' vector ALUs are occupied (SQ_ACTIVE_INST_VALU, 4 cycles per unit): the
     # roof this kernel actually sits under -- ~1.0 means every VALU instruction removed shortens the launch in proportion
     valu_busy = (issue["valu_busy_us"] / issue["kernel_us_profiled"]) if issue and issue.get("valu_busy_us") and issue.get("kernel_us_profiled") else None
     hbm_frac = k[dom]["GBs"] / HBM_PEAK_GBS
     out = {"roofline": {"kernel": k[dom]["name"],
                         "bound": "hbm",        # the roofline `frac` is quoted against (BASELINE.json: HBM roofline of this kernel)
-                        "limiter": (None if valu_frac is None else ("valu" if max(valu_frac, valu_busy or 0.0) > hbm_frac else "hbm")),
+                        "limiter": (None if valu_busy is None else ("valu" if valu_busy > hbm_frac else "hbm")),
                         "achieved": k[dom]["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": hbm_frac, "valu_issue_frac": valu_frac, "valu_busy_frac": valu_busy, "traffic": traffic,
+                        "frac": hbm_frac, "valu_busy_frac": valu_busy, "traffic": traffic,
+                        "traffic_source": (None if traffic is None else "committed rocprofv3 --pmc passes over this command (profiles/r04_*; "
+                                           "tied to this library build and workload shape by hash), not measured in this run"),
                         "issue": issue,
                         "launch_us": launch_us, "alg_bytes_per_launch": k[dom]["bytes"],
                         "launches_timed": k[dom]["launches"],

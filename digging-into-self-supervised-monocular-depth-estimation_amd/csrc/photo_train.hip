@@ -21,47 +21,16 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include "photo_common.hpp"
+#include "photo_train.hpp"
 
 namespace mdx {
 
 constexpr int SW = 60;   // output columns per wave (64 lanes - 2 x 2 halo lanes)
 
-// A/B switch of the builder (build.py passes -D...; the shipped library never reads the environment):
-// 1 = the divisions of the row loop as written-out sequences that share reciprocals (see quot_rcp), 0 = plain `/`
-#ifndef MDX_TRAIN_FASTDIV
-#define MDX_TRAIN_FASTDIV 1
-#endif
-#ifndef MDX_TRAIN_OPAQUE_HIST
-#define MDX_TRAIN_OPAQUE_HIST 1
-#endif
-#ifndef MDX_TRAIN_LAZY_COEF
-#define MDX_TRAIN_LAZY_COEF 1     // SSIM gradient coefficients of a frame only in waves where it can be some lane's arg-min
-#endif
-#ifndef MDX_TRAIN_WAVE_UNIFORM
-#define MDX_TRAIN_WAVE_UNIFORM 0  // per-wave (not per-lane) choice of the u/(W-1), v/(H-1) division form and of the corner border
-                                  // handling: ~70 fewer VALU instructions per step on paper, +1 % time measured (tools/ab_bench_repeat.sh)
-#endif
-#ifndef MDX_TRAIN_WU_NORM
-#define MDX_TRAIN_WU_NORM MDX_TRAIN_WAVE_UNIFORM
-#endif
-#ifndef MDX_TRAIN_WU_CORNER
-#define MDX_TRAIN_WU_CORNER MDX_TRAIN_WAVE_UNIFORM
-#endif
-#ifndef MDX_EVAL_WAVES
-#define MDX_EVAL_WAVES 5          // waves per SIMD of the forward-only form for S <= 2 (96 VGPRs)
-#endif
-#ifndef MDX_TRAIN_LOSS_LDS
-#define MDX_TRAIN_LOSS_LDS 1      // loss partial of a lane: LDS cell + ds_add_f32 (1) or a float register (0)
-#endif
-#ifndef MDX_TRAIN_DEPTH_LDS
-#define MDX_TRAIN_DEPTH_LDS 0     // depth of the rows awaiting their gradient: LDS ring (1) or three registers (0).
-#endif                            // Measured inside the step (tools/ab_bench.sh): the ring costs +8 us (its read sits at the head
-                                  // of the gradient phase, exposed), the registers cost no spill that matters
-
-#ifndef MDX_TRAIN_DEFER_GUP
-#define MDX_TRAIN_DEFER_GUP 0     // 1: the gradient row is stored in the NEXT step (one register across the loop edge)
-#endif
+// Round 4: the A/B switches of rounds 2-3 (MDX_TRAIN_FASTDIV, LAZY_COEF, SLOAD, OPAQUE_*, LATE_*, LOSS_LDS, XCD_GROUP,
+// PRE_LATE on; WU_NORM, WU_CORNER, DEPTH_LDS, DEFER_GUP off) are resolved in the source: the winners are the code, the
+// losers' measurements live in DESIGN.md section 4.1.  What remains switchable: -DMDX_TRAIN_STAMPS (diagnostic build with
+// the in-kernel phase clock) and -DMDX_DEV_SWITCHES (chunk-schedule override for sweeps).
 
 struct TrainArgs {
     int B, H, W, S, nscales;
@@ -88,6 +57,7 @@ struct TrainArgs {
     float *depth0;
     double *loss_part;   // [items]
     float *partP;        // [items][S][12]
+    float *stash;        // LOW form: [items][3 rows][S][64 lanes] float2 -- projected positions (u, v) of the last three warped rows
     unsigned long long *stamps;   // diagnostic builds (-DMDX_TRAIN_STAMPS) only: [items][8] phase cycle sums
 };
 
@@ -106,17 +76,6 @@ struct TrainArgs {
 #define MDX_STAMP(k) do { } while (0)
 #endif
 
-// wave-uniform selection from a by-value kernel-argument array without dynamic indexing (which would send the
-// argument block to scratch)
-template <typename T> MDX_DEV T pick(const T (&v)[MDX_MAX_SCALES], int s)
-{
-    return s == 0 ? v[0] : (s == 1 ? v[1] : (s == 2 ? v[2] : v[3]));
-}
-
-MDX_DEV int pick4(const int (&v)[MDX_MAX_SCALES + 1], int s)
-{
-    return s == 0 ? v[0] : (s == 1 ? v[1] : (s == 2 ? v[2] : v[3]));
-}
 
 template <int CTRL> MDX_DEV float dpp_f(float v)
 {
@@ -153,11 +112,6 @@ template <int N> MDX_DEV void pool3_n(const float (&a)[N][3], float (&out)[N])
     for (int i = 0; i < N; ++i) out[i] = div9(s[i]);
 }
 
-// SSIM of one colour channel of one frame, value AND gradient coefficients in one go.  The value follows ssim_raw()
-// operation for operation (bit-exact); the coefficient triplet of SURVEY appendix A.1 re-uses its intermediates and a
-// hardware reciprocal (gradients carry a 1e-4 tolerance, not bit-exactness).
-struct SsimBoth { float val; SsimGrad g; };
-
 // n / d and 1 / d together.  The correctly rounded float32 quotient as the compiler expands `n / d` for gfx950 is
 //   s = div_scale(...); r0 = rcp(d_s); e0 = fma(-d_s, r0, 1); r1 = fma(e0, r0, r0); q0 = n_s * r1;
 //   e1 = fma(-d_s, q0, n_s); q1 = fma(e1, r1, q0); e2 = fma(-d_s, q1, n_s); q = div_fixup(div_fmas(e2, r1, q1))
@@ -187,35 +141,72 @@ MDX_DEV QuotRcp quot_rcp(float n, float d)
 // subtraction, formed here once per pixel -- or once per STEP by photo_prologue.hip)
 struct TStat { float mu, mu2, sig_y; };
 
-// The same in two halves (MDX_TRAIN_LAZY_COEF): the value now -- keeping what the coefficients need -- and the coefficient
-// triplet later, only in waves where the frame can still be some lane's arg-min.
+// SSIM of one colour channel of one frame in two halves.  The VALUE now: ssim_raw()'s operations in ssim_raw()'s order
+// (bit-exact), keeping the intermediates the gradient needs.  The COEFFICIENT triplet of SURVEY appendix A.1 later, only in
+// waves where the frame can still be some lane's arg-min (in auto-masked regions never): it re-uses those intermediates
+// and quot_rcp's refined reciprocal (gradients carry a 1e-4 tolerance, not bit-exactness).
 struct SsimMid { float A1, A2, B1, B2, q, inv_d, mu_x, raw; };
 
-MDX_DEV float ssim_value_mid(const SsimTerms &s, const TStat &t, SsimMid &m)
+// The value for the THREE colour channels of a frame in lock step: every operation of ssim_raw() (mdx_device.hpp) for channel
+// 0, 1, 2 in turn (the same operations on the same values: the same bits), the quotient by quot_rcp()'s sequence.  A VALU instruction that reads its predecessor's result
+// costs ~2 extra cycles which other waves do not fill (profiles/r02_micro_valu_dep.txt); one channel's value is a chain of
+// ~25 such instructions (the 8 of the quotient back to back), three channels interleaved have none.  The statements are
+// written round-robin and pinned with MDX_LOCKSTEP (an empty asm the three values pass through): the scheduler, which
+// orders for register pressure here, would otherwise put each chain back together.
+#define MDX_LOCKSTEP(a, b, c) asm volatile("" : "+v"(a), "+v"(b), "+v"(c))
+MDX_DEV void ssim_value_mid3(const float (&o)[3][3], const TStat (&t)[3], SsimMid (&m)[3], float (&val)[3])
 {
-    const float mxx = s.mu_x * s.mu_x;
-    const float mxy = s.mu_x * t.mu;
-    const float sig_x = s.ex2 - mxx;
-    const float sig_xy = s.exy - mxy;
-    float a = 2.0f * s.mu_x;
-    a = a * t.mu;
-    m.A1 = a + MDX_C1;
-    float A2 = 2.0f * sig_xy;
-    m.A2 = A2 + MDX_C2;
-    const float n = m.A1 * m.A2;
-    m.B1 = (mxx + t.mu2) + MDX_C1;
-    m.B2 = (sig_x + t.sig_y) + MDX_C2;
-    const float d = m.B1 * m.B2;
-    const QuotRcp qr = quot_rcp(n, d);
-    m.q = qr.q;
-    m.inv_d = qr.r;
-    m.mu_x = s.mu_x;
-    m.raw = (1.0f - qr.q) / 2.0f;
-    return clamp01(m.raw);
+    float mxx[3], mxy[3], sig_x[3], sig_xy[3], a[3], n[3], d[3], r0[3], e0[3], r1[3], q0[3], e1[3], q1[3], e2[3];
+#define MDX_EACH(stmt) { const int c = 0; stmt; } { const int c = 1; stmt; } { const int c = 2; stmt; }
+    MDX_EACH(mxx[c] = o[c][0] * o[c][0])
+    MDX_EACH(mxy[c] = o[c][0] * t[c].mu)
+    MDX_EACH(sig_x[c] = o[c][1] - mxx[c])
+    MDX_EACH(sig_xy[c] = o[c][2] - mxy[c])
+    MDX_EACH(a[c] = 2.0f * o[c][0])
+    MDX_EACH(a[c] = a[c] * t[c].mu)
+    MDX_LOCKSTEP(a[0], a[1], a[2]);
+    MDX_EACH(m[c].A1 = a[c] + MDX_C1)
+    MDX_EACH(m[c].A2 = 2.0f * sig_xy[c])
+    MDX_EACH(m[c].A2 = m[c].A2 + MDX_C2)
+    MDX_EACH(m[c].B1 = (mxx[c] + t[c].mu2))
+    MDX_EACH(m[c].B1 = m[c].B1 + MDX_C1)
+    MDX_EACH(m[c].B2 = (sig_x[c] + t[c].sig_y))
+    MDX_EACH(m[c].B2 = m[c].B2 + MDX_C2)
+    MDX_EACH(n[c] = m[c].A1 * m[c].A2)
+    MDX_EACH(d[c] = m[c].B1 * m[c].B2)
+    MDX_LOCKSTEP(d[0], d[1], d[2]);
+    // quot_rcp(n, d), three at a time
+    MDX_EACH(r0[c] = __builtin_amdgcn_rcpf(d[c]))
+    MDX_LOCKSTEP(r0[0], r0[1], r0[2]);
+    MDX_EACH(e0[c] = __builtin_fmaf(-d[c], r0[c], 1.0f))
+    MDX_LOCKSTEP(e0[0], e0[1], e0[2]);
+    MDX_EACH(r1[c] = __builtin_fmaf(e0[c], r0[c], r0[c]))
+    MDX_LOCKSTEP(r1[0], r1[1], r1[2]);
+    MDX_EACH(q0[c] = n[c] * r1[c])
+    MDX_LOCKSTEP(q0[0], q0[1], q0[2]);
+    MDX_EACH(e1[c] = __builtin_fmaf(-d[c], q0[c], n[c]))
+    MDX_LOCKSTEP(e1[0], e1[1], e1[2]);
+    MDX_EACH(q1[c] = __builtin_fmaf(e1[c], r1[c], q0[c]))
+    MDX_LOCKSTEP(q1[0], q1[1], q1[2]);
+    MDX_EACH(e2[c] = __builtin_fmaf(-d[c], q1[c], n[c]))
+    MDX_LOCKSTEP(e2[0], e2[1], e2[2]);
+    MDX_EACH(m[c].q = __builtin_fmaf(e2[c], r1[c], q1[c]))
+    MDX_LOCKSTEP(m[0].q, m[1].q, m[2].q);
+    MDX_EACH(m[c].inv_d = r1[c])
+    MDX_EACH(m[c].mu_x = o[c][0])
+    MDX_EACH(m[c].raw = 1.0f - m[c].q)
+    MDX_LOCKSTEP(m[0].raw, m[1].raw, m[2].raw);
+    MDX_EACH(m[c].raw = m[c].raw / 2.0f)
+    MDX_LOCKSTEP(m[0].raw, m[1].raw, m[2].raw);
+    MDX_EACH(val[c] = clamp01(m[c].raw))
+#undef MDX_EACH
 }
 
+// gradient-only arithmetic may fuse multiply-adds (tolerance 1e-4; the VALUES stay unfused: -ffp-contract=off)
+#define MDX_GRAD_FP _Pragma("clang fp contract(fast)")
 MDX_DEV SsimGrad ssim_coef_mid(const SsimMid &m, const TStat &t, float gscale)
 {
+    MDX_GRAD_FP
     const float Ln = -0.5f * m.inv_d, Ld = 0.5f * m.q * m.inv_d;
     const float dA1 = Ln * m.A2, dA2 = Ln * m.A1, dB1 = Ld * m.B2, dB2 = Ld * m.B1;
     const bool pass = m.raw >= 0.f && m.raw <= 1.f;   // clamp passes the gradient on the closed interval
@@ -225,43 +216,6 @@ MDX_DEV SsimGrad ssim_coef_mid(const SsimMid &m, const TStat &t, float gscale)
     g.beta = gs * dB2;
     g.gamma = gs * 2.0f * dA2;
     return g;
-}
-
-MDX_DEV SsimBoth ssim_both(const SsimTerms &s, const TStat &t, float gscale)
-{
-    const float mxx = s.mu_x * s.mu_x;
-    const float mxy = s.mu_x * t.mu;
-    const float sig_x = s.ex2 - mxx;
-    const float sig_y = t.sig_y;
-    const float sig_xy = s.exy - mxy;
-    float a = 2.0f * s.mu_x;
-    a = a * t.mu;
-    const float A1 = a + MDX_C1;
-    float A2 = 2.0f * sig_xy;
-    A2 = A2 + MDX_C2;
-    const float n = A1 * A2;
-    const float B1 = (mxx + t.mu2) + MDX_C1;
-    const float B2 = (sig_x + sig_y) + MDX_C2;
-    const float d = B1 * B2;
-#if MDX_TRAIN_FASTDIV
-    const QuotRcp qr = quot_rcp(n, d);
-    const float q = qr.q, inv_d = qr.r;
-#else
-    const float q = n / d;
-    float inv_d = __builtin_amdgcn_rcpf(d);                              // 1 ulp
-    inv_d = __builtin_fmaf(__builtin_fmaf(-d, inv_d, 1.0f), inv_d, inv_d);   // one Newton step
-#endif
-    const float raw = (1.0f - q) / 2.0f;
-    SsimBoth r;
-    r.val = clamp01(raw);
-    const float Ln = -0.5f * inv_d, Ld = 0.5f * q * inv_d;
-    const float dA1 = Ln * A2, dA2 = Ln * A1, dB1 = Ld * B2, dB2 = Ld * B1;
-    const bool pass = raw >= 0.f && raw <= 1.f;   // clamp passes the gradient on the closed interval
-    const float gs = pass ? gscale : 0.f;
-    r.g.alpha = gs * 2.0f * (t.mu * (dA1 - dA2) + s.mu_x * (dB1 - dB2));
-    r.g.beta = gs * dB2;
-    r.g.gamma = gs * 2.0f * dA2;
-    return r;
 }
 
 // ---- the geometry's divisions with the same written-out sequence ----
@@ -298,59 +252,28 @@ MDX_DEV Proj project_point_train(const float *__restrict__ P, float X0, float X1
     }
     Proj p;
     p.z = q[2] + eps;
-#if MDX_TRAIN_FASTDIV
     if (wave_all_normal(p.z)) {
         const float r1 = refined_rcp(p.z);
         p.u = quot_with(q[0], p.z, r1);
         p.v = quot_with(q[1], p.z, r1);
-    } else
-#endif
-    {
+    } else {
         p.u = q[0] / p.z;
         p.v = q[1] / p.z;
     }
     // u / (W-1), v / (H-1): div_norm() picks per LANE between the verified 3-instruction constant division and the IEEE
-    // divide -- as a select, so both run.  Here the choice is made once per wave (a lane outside the verified range, i.e.
-    // |x| <= 1e-30 or >= 3e38, sends the wave through `/`): the 2 x 11 instructions of the unused divides are gone.
-    float nx, ny;
-    const float au = fabsf(p.u), av = fabsf(p.v);
-    const bool fast_ok = nd.w.fast && nd.h.fast && au > 1e-30f && au < 3.0e38f && av > 1e-30f && av < 3.0e38f;
-    if (MDX_TRAIN_WU_NORM && __builtin_amdgcn_ballot_w64(!fast_ok) == 0) {
-        nx = div_by_const(p.u, nd.w.b, nd.w.r);
-        ny = div_by_const(p.v, nd.h.b, nd.h.r);
-    } else {
-        nx = div_norm(p.u, nd.w);
-        ny = div_norm(p.v, nd.h);
-    }
-    p.gx = (nx - 0.5f) * 2.0f;
-    p.gy = (ny - 0.5f) * 2.0f;
+    // divide (a select: both run).  A per-WAVE choice was measured in round 3 and is not faster.
+    p.gx = (div_norm(p.u, nd.w) - 0.5f) * 2.0f;
+    p.gy = (div_norm(p.v, nd.h) - 0.5f) * 2.0f;
     return p;
 }
 
-// load_corners() (mdx_device.hpp) with the border handling decided per wave: a tap on the image's last column / last row
-// needs the pair shifted / the lower pair zeroed (four selects per channel); only waves that hold such a tap pay for them.
-MDX_DEV Corners load_corners_train(const float *__restrict__ img, int H, int W, const Tap &t, bool border_wave)
-{
-    if (!MDX_TRAIN_WU_CORNER || border_wave) return load_corners(img, H, W, t);
-    const unsigned o0 = (unsigned)(t.y0 * W + t.x0) * 4u, o1 = o0 + (unsigned)W * 4u;
-    const char *base = reinterpret_cast<const char *>(img);
-    const float2_a4 top = *reinterpret_cast<const float2_a4 *>(base + o0);
-    const float2_a4 bot = *reinterpret_cast<const float2_a4 *>(base + o1);
-    Corners c;
-    c.nw = top.x; c.ne = top.y; c.sw = bot.x; c.se = bot.y;
-    return c;
-}
-
-// geom_from_disp() (photo_common.hpp) likewise
+// geom_from_disp() (photo_common.hpp) with the written-out reciprocal
 MDX_DEV PixelGeom geom_from_disp_train(const mdx_desc &d, float up, const float *__restrict__ invK_b, int px, int py)
 {
     PixelGeom g;
     const float sd = scaled_disp(up, d.disp_a, d.disp_b);
-#if MDX_TRAIN_FASTDIV
     if (wave_all_normal(sd)) g.depth = quot_with(1.0f, sd, refined_rcp(sd));
-    else
-#endif
-        g.depth = 1.0f / sd;
+    else g.depth = 1.0f / sd;
     pixel_ray(invK_b, (float)px, (float)py, g.r);
     g.X0 = g.depth * g.r[0];
     g.X1 = g.depth * g.r[1];
@@ -361,19 +284,9 @@ MDX_DEV PixelGeom geom_from_disp_train(const mdx_desc &d, float up, const float 
 // ---- the item's 3x4 matrices as TRANSIENT scalars ----
 // P (S x 12) and invK (12) are wave-uniform.  Held in scalar registers for the whole item they take 36 of the ~100
 // SGPRs; with the row pointers of a step on top the allocator spilled 61 values to VGPR lanes and paid ~90
-// v_readlane / v_writelane (VALU issue slots, plus hazard s_nops) per step.  MDX_TRAIN_SLOAD re-reads them through
-// the scalar cache where they are used (s_load_dwordx4 x3 per matrix, scalar unit, no VALU slot) so that they are dead
-// in between: 61 -> 41 spilled SGPRs, 120 -> 45 v_readlane, 165 -> 116 s_nop cycles in the kernel, -1.5 % time.
-// (=0 keeps the old form for A/B builds.)
-#ifndef MDX_TRAIN_SLOAD
-#define MDX_TRAIN_SLOAD 1
-#endif
-#ifndef MDX_TRAIN_OPAQUE_HW
-#define MDX_TRAIN_OPAQUE_HW 1
-#endif
-#ifndef MDX_TRAIN_XCD_GROUP
-#define MDX_TRAIN_XCD_GROUP 1
-#endif
+// v_readlane / v_writelane (VALU issue slots, plus hazard s_nops) per step.  They are re-read through the scalar cache
+// where they are used (s_load_dwordx4 x3 per matrix, scalar unit, no VALU slot) so that they are dead in between:
+// 61 -> 41 spilled SGPRs, 120 -> 45 v_readlane, 165 -> 116 s_nop cycles in the kernel, -1.5 % time.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
 typedef unsigned u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
@@ -418,11 +331,7 @@ MDX_DEV float ssim_val(const SsimTerms &s, const TStat &t)
     const float B1 = (mxx + t.mu2) + MDX_C1;
     const float B2 = (sig_x + sig_y) + MDX_C2;
     const float d = B1 * B2;
-#if MDX_TRAIN_FASTDIV
     const float q = quot_rcp(n, d).q;
-#else
-    const float q = n / d;
-#endif
     return clamp01((1.0f - q) / 2.0f);
 }
 
@@ -431,19 +340,40 @@ MDX_DEV float ssim_val(const SsimTerms &s, const TStat &t)
 // without the coefficient histories, the stash and the gradient phase -- every scale's forward in ONE launch.
 // PRE = true: the step's prologue kernel has evaluated what the scales share (target statistics, best identity channel):
 // they are loaded (8 dwords and a byte per pixel) instead of re-derived (6 pools) / re-read (2 S dwords) per scale.
-template <int S, bool GRAD, bool PRE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <= 2 ? 3 : 2) : (S <= 3 ? 4 : 3), GRAD ? (S <= 2 ? 3 : 2) : 8))) void photometric_train_kernel(TrainArgs a)
+// Round 4, the LOW form of the training kernel (S >= 3): one more wave per SIMD.  The launch time follows the resident
+// waves (S = 2, same code: 2 waves 261 us, 3 waves 204 us), and S = 3 (mono + stereo, BASELINE configs[4]) sat at 2 waves:
+// 203 registers and 18.7 KB of LDS per wave.  State that is touched once per step or less leaves the registers / the LDS:
+//   * the d(P) accumulators (9 S values per lane, touched only in the gradient phase): LDS cells, read - add - write at the
+//     lane's own address (ds_add_f32, the unit's atomic path, DOUBLED the launch time: 18 per frame and step);
+//   * the two older rows of the SSIM coefficient history (18 values per lane, read only by the gradient phase): an LDS
+//     ring; the newest row stays in registers through the step that forms it and is written behind its gradient phase;
+//   * the stash ring (sampling derivatives + projected position of the last three warped rows, 18 KB per wave at S = 3: what
+//     capped the LDS occupancy) is gone.  Only the projected position (u, v) of a warped pixel is kept -- 8 bytes per frame
+//     in a per-item ring in GLOBAL memory (4.6 KB per wave: L2-resident) -- and the gradient phase re-derives the tap from it
+//     (the forward's own arithmetic on the forward's own bits: the same tap), re-reads the corners (cache hits) and forms
+//     the sampling derivatives itself: only in waves where the frame is some lane's arg-min, not for every frame and step.
+// S = 3: 203 -> 146 registers, 18.7 -> 11.8 KB LDS: 3 waves per SIMD, 340 -> 297 us on bench.py's mono + stereo batch.
+// S <= 2 keeps the register form: there the same machinery costs more than a fourth wave gives (198 us in
+// registers at 3 waves; LOW 251 us at 4 waves, 241 us with the full stash in the global ring, 223 us at 3 waves).
+constexpr bool train_low(int S, bool grad) { return grad && S >= 3; }
+constexpr int train_waves(int S, bool grad)
 {
+    return grad ? (S <= 2 ? 3 : (S == 3 ? 3 : 2)) : (S <= 3 ? 4 : 3);
+}
+template <int S, bool GRAD, bool PRE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(train_waves(S, GRAD), GRAD ? train_waves(S, GRAD) : 8))) void photometric_train_kernel(TrainArgs a)
+{
+    constexpr bool LOW = train_low(S, GRAD);
     // per-lane stash ring: [row slot][2f] = (d colour_c / du, u), [2f+1] = (d colour_c / dv, v) of frame f
-    __shared__ float4 s_stash[GRAD ? 3 : 1][GRAD ? 2 * S : 1][GRAD ? 64 : 1];
+    // (LOW: in global memory, a.stash)
+    __shared__ float4 s_stash[(GRAD && !LOW) ? 3 : 1][(GRAD && !LOW) ? 2 * S : 1][(GRAD && !LOW) ? 64 : 1];
+    __shared__ float s_acc[LOW ? 9 * S : 1][LOW ? 64 : 1];      // LOW: d(P) accumulators [f * 9 + {A, B, C} * 3 + i][lane]
+    __shared__ float s_ch[LOW ? 2 : 1][LOW ? 9 : 1][LOW ? 64 : 1];   // LOW: coefficient rows sr-2, sr-1 (slot = step parity)
     // loss partial of each lane: an LDS cell, updated by one ds_add_f32 per row (own address: sequential, deterministic).
     // As a register it was the value the allocator spilled in the <2, GRAD, PRE> instantiation -- a scratch load,
     // s_waitcnt vmcnt(0), add, scratch store in every step.  float32: at most 44 addends in [0, 1] per lane (error ~1e-7
     // of the lane's sum, independent between the ~1.5 M lanes); lanes, items and scales are summed in float64.
     __shared__ float s_loss[64];
-#if MDX_TRAIN_DEPTH_LDS
-    __shared__ float s_depth[GRAD ? 3 : 1][GRAD ? 64 : 1];     // depth of the rows in the stash ring (three registers less)
-#endif
 
     const int lane = threadIdx.x;
     // ---- work item: level-major order (see TrainArgs), dispatched in block order.  An XCD-contiguous order inside each
@@ -455,7 +385,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
     const int lev = item_d >= a.lev_item0[2] ? 2 : (item_d >= a.lev_item0[1] ? 1 : 0);
     const int lev_first = lev == 2 ? a.lev_item0[2] : (lev == 1 ? a.lev_item0[1] : a.lev_item0[0]);
     const int lev_rows = lev == 2 ? a.lev_r[2] : (lev == 1 ? a.lev_r[1] : a.lev_r[0]);
-#if MDX_TRAIN_XCD_GROUP
     // Workgroup i runs on XCD i % 8.  The scales of one (chunk, image, strip) read the same target / source / identity
     // rows: their ids share the residue mod 8 and are adjacent (start together), so three of the four find those
     // lines in the XCD's L2.  Groups go round the XCDs one by one -- every XCD keeps the same mix of costs (what the
@@ -477,12 +406,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
     const int kk = grp / per_scale, gcol = grp % per_scale;
     const int strip = gcol % a.nstrips;
     const int b = gcol / a.nstrips;
-#else
-    const int kk = (item_d - lev_first) / a.ncols, colid = (item_d - lev_first) % a.ncols;
-    const int strip = colid % a.nstrips;
-    const int b = (colid / a.nstrips) % a.B;
-    const int scale = colid / (a.nstrips * a.B);
-#endif
     const int chunk = (lev == 2 ? a.lev_k0[2] : (lev == 1 ? a.lev_k0[1] : a.lev_k0[0])) + kk;
     // slot of the item's partials: the items of one (scale, image) contiguous, whatever the dispatch order
     const unsigned item = (unsigned)(((scale * a.B + b) * a.nchunks + chunk) * a.nstrips + strip);
@@ -493,22 +416,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
     d.w = pick(a.w, scale);
     const int H = d.H, W = d.W;
     const size_t HW0 = (size_t)H * W;
-    // Inside the row loop the plane size is made opaque once per step (MDX_TRAIN_OPAQUE_HW): otherwise the dozen plane
+    // Inside the row loop the plane size is made opaque once per step: otherwise the dozen plane
     // bases `tensor + (b*planes + c)*HW` are hoisted out of the loop as 64-bit scalars -- and spilled to VGPR lanes;
     // recomputing them per step costs scalar-unit instructions only.
     unsigned HW = (unsigned)HW0;
     const float *disp_b = pick(a.disp, scale) + (size_t)b * d.h * d.w;
     const float *P_s = pick(a.P, scale);
     const float *noise_s = pick(a.noise, scale);
-    // MDX_TRAIN_LATE_PICK: the per-scale output pointers (and the best-identity map) are fetched from the kernel-argument
+    // The per-scale output pointers (and the best-identity map) are fetched from the kernel-argument
     // segment WHERE THEY ARE USED -- one s_load_dwordx2 at (array offset + 8 * scale), two scalar registers for a few
     // instructions.  Held across the row loop they were loop-invariant 64-bit scalars the allocator spilled to VGPR lanes,
     // and every use paid two v_readlane (8.5 cycles each on the vector ALU that bounds this kernel).  (Re-deriving them with
     // pick() -- four pointer loads and a select chain -- at the use sites made it worse: 28 -> 49 spilled scalars.)
-#ifndef MDX_TRAIN_LATE_PICK
-#define MDX_TRAIN_LATE_PICK 1
-#endif
-#if MDX_TRAIN_LATE_PICK
     const char *const kargs = (const char *)__builtin_amdgcn_kernarg_segment_ptr();     // TrainArgs is the kernel's only argument
     const unsigned scale8 = 8u * (unsigned)scale;
 #define MDX_LATE(T, arr)                                                                                          \
@@ -519,23 +438,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
         typedef __attribute__((address_space(1))) char *gp_;       /* a global pointer: saddr stores, not flat ones */ \
         return (T)(gp_)v_;                                                                                        \
     }())
-#else
-    uint8_t *idx_s = pick(a.idx, scale);
-    float *gup_s = pick(a.gup, scale);
-    float *to_opt_s = pick(a.to_opt, scale);
-    const float *bidfi_l = pick(a.bidfi, scale);
-#define MDX_LATE(T, arr) ((T)MDX_LATE_##arr)
-#define MDX_LATE_idx idx_s
-#define MDX_LATE_gup gup_s
-#define MDX_LATE_to_opt to_opt_s
-#define MDX_LATE_bidfi bidfi_l
-#endif
     const float *invK_b = a.invK + b * 16;
     const float *tgt_b = a.target + (size_t)b * 3 * HW0;
-#ifndef MDX_TRAIN_LATE_FLAGS
-#define MDX_TRAIN_LATE_FLAGS 1
-#endif
-#if MDX_TRAIN_LATE_FLAGS
     // the item's wave-uniform conditions, re-derived from one scalar WHERE THEY ARE USED (a bit test on the scalar unit):
     // as loop-invariant booleans they lived in 64-bit lane masks, which the allocator spilled to VGPR lanes and fetched
     // back with two v_readlane per use
@@ -549,11 +453,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
 #define automask item_bit(1u)
 #define premul item_bit(2u)
 #define same_res item_bit(4u)
-#else
-    const bool automask = (d.flags & MDX_FLAG_AUTOMASK) != 0;
-    const bool premul = (d.flags & MDX_FLAG_UPSAMPLE_PREMUL) != 0;
-    const bool same_res = d.h == H && d.w == W;
-#endif
     const Norm2 nd = desc_norm(d);
 
     // ---- per-lane constants: the column ----
@@ -583,28 +482,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
 
     // ---- the item's matrices, once, as wave-uniform scalars (inside the loop they would be re-fetched through vector
     //      memory every row and consumed at once: two exposed cache round trips per row) ----
-#if MDX_TRAIN_SLOAD
     const float *Pp[S];
 #pragma unroll
     for (int f = 0; f < S; ++f) Pp[f] = uniform_ptr(P_s + ((size_t)f * d.B + b) * 12);
     const float *iKp = uniform_ptr(invK_b);
-#else
-    float Pm[S][12], iK[12];
-#pragma unroll
-    for (int f = 0; f < S; ++f)
-#pragma unroll
-        for (int k = 0; k < 12; ++k)
-            Pm[f][k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(
-                __builtin_bit_cast(int, P_s[((size_t)f * d.B + b) * 12 + k])));
-#pragma unroll
-    for (int k = 0; k < 12; ++k)
-        iK[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, invK_b[k])));
-#endif
 
     // ---- histories (registers) ----
     float xh[3][S][3];   // warped colours, rows wr-2 .. wr
     float yh[3][3];      // target colours, same rows
-    float ch[3][3][3];   // [row][channel][alpha,beta,gamma] of the arg-min frame, rows sr-2 .. sr
+    constexpr int CR = LOW ? 1 : 3, CN = CR - 1;   // coefficient rows held in registers; index of the newest
+    float ch[CR][3][3];  // [row][channel][alpha,beta,gamma] of the arg-min frame, rows sr-2 .. sr (LOW: row sr only)
     int selp = 0;        // arg-min frame + 1 (0 = none) of rows sr-2, sr-1, sr in bits 0-3, 4-7, 8-11
     int flp = 0;         // grid_sample pass flags (bit 2f: x inside, 2f+1: y inside) of rows wr-2, wr-1, wr in bytes 0-2
 #pragma unroll
@@ -614,26 +501,47 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
             yh[j][c] = 0.f;
 #pragma unroll
             for (int f = 0; f < S; ++f) xh[j][f][c] = 0.f;
+            if (j < CR)
 #pragma unroll
-            for (int k = 0; k < 3; ++k) ch[j][c][k] = 0.f;
+                for (int k = 0; k < 3; ++k) ch[j][c][k] = 0.f;
         }
     }
-#if !MDX_TRAIN_DEPTH_LDS
+    if constexpr (LOW) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) s_ch[0][k][lane] = s_ch[1][k][lane] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9 * S; ++k) s_acc[k][lane] = 0.f;
+    }
     float dph[3] = {0.f, 0.f, 0.f};
-#endif
     // d(P) accumulators.  With X_j = depth * r_j and the pixel ray r = invK (px, py, 1) linear in the pixel, the twelve
     // sums of a frame follow from nine: A_i = sum gq_i*depth, Bv_i = sum py*gq_i*depth, C_i = sum gq_i (px is a
     // constant of the lane and is applied at the end).
-    float accA[S][3], accB[S][3], accC[S][3];
+    constexpr int AS = LOW ? 1 : S;
+    float accA[AS][3], accB[AS][3], accC[AS][3];
+    if constexpr (!LOW)
 #pragma unroll
     for (int f = 0; f < S; ++f)
 #pragma unroll
         for (int i = 0; i < 3; ++i) accA[f][i] = accB[f][i] = accC[f][i] = 0.f;
-#if MDX_TRAIN_LOSS_LDS
+    // LOW: the item's (u, v) ring in global memory; a slot is S planes of 64 float2.  A slot's base is handed to the
+    // accesses as an OPAQUE SCALAR (as the target planes are, below): left to the compiler, `ring + 16 * lane` is hoisted
+    // out of the loop as a 64-bit per-lane pointer (two registers, spilled) and the slot offset added per lane in 64 bits
+    const unsigned long long stash_item =
+        LOW ? (unsigned long long)(reinterpret_cast<char *>(a.stash) + (size_t)item * (3u * S * 512u)) : 0ull;
+    auto stash_slot = [&](int slot, int plane) {
+        unsigned long long v = stash_item + (unsigned)slot * (S * 512u) + (unsigned)plane * 512u;
+        asm volatile("" : "+s"(v));
+        typedef __attribute__((address_space(1))) float2 *gptr;
+        return (float2 *)(gptr)v;
+    };
+    // ... and the lane's element index as an opaque 32-bit value formed next to the access: hoisted out of the loop it becomes a
+    // zero-extended 64-bit pair, and the access loses its scalar-base + 32-bit-offset form (v_lshl_add_u64 per access)
+    auto stash_lane = [&](unsigned plane_off) {
+        unsigned v = (unsigned)lane;
+        asm volatile("" : "+v"(v));
+        return v + plane_off;
+    };
     s_loss[lane] = 0.f;
-#else
-    float acc_reg = 0.f;
-#endif
 
     // ---- prefetch registers: the loads of the NEXT step whose addresses do not depend on computed data ----
     float pf_y[3], pf_d[4], pf_id[S], pf_nz[S];
@@ -682,15 +590,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
         }
     };
     prefetch_warp_row(r0 - (GRAD ? 2 : 1));
-#ifndef MDX_TRAIN_PRE_LATE
-#define MDX_TRAIN_PRE_LATE 1      // PRE: fetch the SSIM row's statistics inside the step (behind the corner loads), not a step ahead
-#endif
-    if (!(PRE && MDX_TRAIN_PRE_LATE)) prefetch_ssim_row(r0 - (GRAD ? 3 : 2));
+    // (PRE fetches the SSIM row's statistics inside the step, behind the corner loads, not a step ahead)
+    if (!PRE) prefetch_ssim_row(r0 - (GRAD ? 3 : 2));
 
-#if MDX_TRAIN_DEFER_GUP
-    float gup_val = 0.f;
-    int gup_row = -1;
-#endif
 #ifdef MDX_TRAIN_STAMPS
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long st_last = __builtin_amdgcn_s_memtime();
@@ -704,15 +606,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
         const int sr = wr - 1;            // row whose SSIM / arg-min / coefficients are formed
         const int gr = wr - 2;            // row whose gradient is formed
         const int slot_w = t % 3, slot_r = (t + 1) % 3;
-#if MDX_TRAIN_OPAQUE_HW
         asm volatile("" : "+s"(HW));
-#endif
-#if MDX_TRAIN_SLOAD
         SRows s_iK, s_P[S];
         sload12(iKp, s_iK);
 #pragma unroll
         for (int f = 0; f < S; ++f) sload12(Pp[f], s_P[f]);
-#endif
 
         // ================= (1) warp row wr =================
 #pragma unroll
@@ -734,18 +632,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
                 const UpTap ty = up_tap((float)d.h / (float)H, pyr, d.h);
                 up = up_combine(pf_d[0], pf_d[1], pf_d[2], pf_d[3], ty, tx_tap(), premul);
             }
-#if MDX_TRAIN_SLOAD
             float iK[12], Pm[S][12];
             swait12(s_iK, iK);
 #pragma unroll
             for (int f = 0; f < S; ++f) swait12(s_P[f], Pm[f]);
-#endif
             const PixelGeom g = geom_from_disp_train(d, up, iK, pxr, pyr);
-#if MDX_TRAIN_DEPTH_LDS
-            if constexpr (GRAD) s_depth[slot_w][lane] = g.depth;      // the gradient of this row (two steps on) needs it
-#else
             dph[0] = dph[1]; dph[1] = dph[2]; dph[2] = g.depth;
-#endif
             if (a.depth0 && scale == 0 && out_lane && wr >= r0 && wr < r1)
                 at32(a.depth0 + (size_t)b * HW, (unsigned)(pyr * W + pxr)) = g.depth;
             // taps of every frame first, then ALL corner loads, then (while they fly) the next step's prefetches
@@ -759,22 +651,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
             }
 #pragma unroll
             for (int f = 0; f < S; ++f) {
-                // does any lane of the wave tap the last column or the last row of this frame?  (wave-uniform)
-                const bool border_wave = __builtin_amdgcn_ballot_w64(tp[f].x0 >= W - 1 || tp[f].y0 >= H - 1) != 0;
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
-                    cn[f][c] = load_corners_train(a.src.img[f] + ((size_t)b * 3 + c) * HW, H, W, tp[f], border_wave);
+                    cn[f][c] = load_corners(a.src.img[f] + ((size_t)b * 3 + c) * HW, H, W, tp[f]);
             }
             prefetch_warp_row(wr + 1);
-#if MDX_TRAIN_DEFER_GUP
-            if constexpr (GRAD) {
-                if (gup_row >= 0 && out_lane) at32(MDX_LATE(float *, gup) + (size_t)b * HW, (unsigned)(gup_row * W + pxr)) = gup_val;
-                gup_row = -1;
-            }
-#endif
             // PRE: this step's SSIM row -- three loads whose latency the sampling arithmetic below covers; fetched a step
             // ahead they would hold eight more registers across the loop edge (6 spills at 168 VGPRs)
-            if (PRE && MDX_TRAIN_PRE_LATE) prefetch_ssim_row(sr);
+            if (PRE) prefetch_ssim_row(sr);
             MDX_STAMP(0);   // geometry, taps, load issue
             int fl = 0;
 #pragma unroll
@@ -785,12 +669,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     xh[2][f][c] = sample(cn[f][c], tp[f]);
-                    if constexpr (GRAD) {
+                    if constexpr (GRAD && !LOW) {
                         du[c] = (cn[f][c].ne - cn[f][c].nw) * dy1 + (cn[f][c].se - cn[f][c].sw) * dy0;
                         dv[c] = (cn[f][c].sw - cn[f][c].nw) * dx1 + (cn[f][c].se - cn[f][c].ne) * dx0;
                     }
                 }
-                if constexpr (GRAD) {
+                if constexpr (LOW) {
+                    at32(stash_slot(slot_w, f), stash_lane(0u)) = make_float2(pr[f].u, pr[f].v);
+                } else if constexpr (GRAD) {
                     s_stash[slot_w][2 * f][lane] = make_float4(du[0], du[1], du[2], pr[f].u);
                     s_stash[slot_w][2 * f + 1][lane] = make_float4(dv[0], dv[1], dv[2], pr[f].v);
                     fl |= (tp[f].inx ? 1 : 0) << (2 * f);
@@ -807,7 +693,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
 #pragma unroll
             for (int c = 0; c < 3; ++c)
 #pragma unroll
-                for (int k = 0; k < 3; ++k) { ch[0][c][k] = ch[1][c][k]; ch[1][c][k] = ch[2][c][k]; }
+                for (int k = 0; k < 3; ++k)
+                    if constexpr (!LOW) { ch[0][c][k] = ch[1][c][k]; ch[1][c][k] = ch[2][c][k]; }
         }
         if (t >= 2 && sr >= 0 && sr < H) {
             // every product a pool reads through DPP is formed in a block of its own, pinned ahead of the pools by a
@@ -861,9 +748,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
             for (int f = 0; f < S; ++f) {
                 float ss[3], ad[3];
                 SsimGrad sg[3];
-#if MDX_TRAIN_LAZY_COEF
                 SsimMid mid[3];
-#endif
+                float po[3][3];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     float q[3][3], o[3];
@@ -875,27 +761,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     pool3_n<3>(q, o);
-                    SsimTerms st;
-                    st.mu_x = o[0]; st.ex2 = o[1]; st.exy = o[2];
                     if constexpr (GRAD) {
-#if MDX_TRAIN_LAZY_COEF
-                        ss[c] = ssim_value_mid(st, ts[c], mid[c]);
-#else
-                        const SsimBoth sb = ssim_both(st, ts[c], 0.85f / 3.0f);
-                        ss[c] = sb.val;
-                        sg[c] = sb.g;
-#endif
+                        po[c][0] = o[0]; po[c][1] = o[1]; po[c][2] = o[2];
                     } else {
+                        SsimTerms st;
+                        st.mu_x = o[0]; st.ex2 = o[1]; st.exy = o[2];
                         ss[c] = ssim_val(st, ts[c]);
                     }
                     ad[c] = fabsf(yh[1][c] - xh[1][f][c]);
                 }
+                if constexpr (GRAD) ssim_value_mid3(po, ts, mid, ss);
                 const float rl = reprojection_combine(ss, ad);
                 const bool better = f == 0 || rl < best_r;
                 best_r = better ? rl : best_r;
                 fr = better ? f : fr;
                 if constexpr (GRAD) {
-#if MDX_TRAIN_LAZY_COEF
                     // the frame can end as a lane's arg-min only where it beats the frames before it AND the best identity
                     // channel (later frames can only take lanes away); where it ends as the arg-min, `better` held here, so
                     // the candidate selected below is the one the gradient phase needs.  Wave-uniform skip otherwise: in
@@ -911,14 +791,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
                             cand[c][2] = better ? sg[c].gamma : cand[c][2];
                         }
                     }
-#else
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        cand[c][0] = better ? sg[c].alpha : cand[c][0];
-                        cand[c][1] = better ? sg[c].beta : cand[c][1];
-                        cand[c][2] = better ? sg[c].gamma : cand[c][2];
-                    }
-#endif
                 }
             }
             // concat [ident + 1e-5*noise, reproj] and torch.min's first-minimum rule (processor.py:194-204)
@@ -936,89 +808,114 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) ch[2][c][k] = keep ? cand[c][k] : 0.f;
+                    for (int k = 0; k < 3; ++k) ch[CN][c][k] = keep ? cand[c][k] : 0.f;
                 selp |= (fr + 1) << 8;
             }
-#if MDX_TRAIN_OPAQUE_HIST
             // `best` and `bi` are pinned in front of the store branch by an empty volatile asm.  In the forward-only form
             // nothing but the stores below consumes them, and the optimiser then SINKS the whole SSIM evaluation into that
             // lane-divergent branch -- except the neighbour-lane reads, which are convergent and stay outside; the backend
             // folds a DPP read into the add that consumes it only within one basic block, so all 108 of them became
             // separate v_mov_dpp (and 76 values were spilled).
             asm volatile("" : "+v"(best), "+v"(bi));
-#endif
             if (out_lane && sr >= r0 && sr < r1) {
                 const unsigned po = (unsigned)(sr * W + pxr);
                 at32(MDX_LATE(uint8_t *, idx) + (size_t)b * HW, po) = (uint8_t)bi;
                 float *const to_opt_p = MDX_LATE(float *, to_opt);
                 if (to_opt_p) at32(to_opt_p + (size_t)b * HW, po) = best;
-#if MDX_TRAIN_LOSS_LDS
                 // the cell's address from a lane id formed HERE (two v_mbcnt, volatile so that they are not hoisted): as a
                 // loop-invariant register it was the next value to be spilled
                 unsigned lid;
                 asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lid));
                 (void)__hip_atomic_fetch_add(&s_loss[lid], best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-#else
-                acc_reg += best;
-#endif
             }
         } else if constexpr (GRAD) {
 #pragma unroll
             for (int c = 0; c < 3; ++c)
 #pragma unroll
-                for (int k = 0; k < 3; ++k) ch[2][c][k] = 0.f;
+                for (int k = 0; k < 3; ++k) ch[CN][c][k] = 0.f;
         }
-        if (!(PRE && MDX_TRAIN_PRE_LATE)) prefetch_ssim_row(sr + 1);   // behind its last use: one step of cover, no second copy of the values
+        if (!PRE) prefetch_ssim_row(sr + 1);   // behind its last use: one step of cover, no second copy of the values
 
         MDX_STAMP(2);   // SSIM phase
         // ================= (3) gradient of row gr =================
         if constexpr (GRAD) {
         if (t >= 4) {
+        // everything in this block feeds gradients only (bar: 1e-4 against the oracle, not bit-exactness): the compiler may
+        // fuse its multiply-adds -- the file is built with -ffp-contract=off for the sake of the VALUES
+        MDX_GRAD_FP
         const float wy0 = gr == 1 ? 2.f : 1.f, wy2 = gr == H - 2 ? 2.f : 1.f;   // reflection-pad fold (y)
-#if MDX_TRAIN_SLOAD
-        float iK[12], Pm[S][12];
+        float iK[12], Pm[LOW ? 1 : S][12];
         {   // re-read right here: issued before the SSIM phase, or kept from the top of the step, the longer live
-            // ranges cost more in spills than the exposed scalar-cache latency (300 us against 314 / 312 us, kbench)
-            SRows g_iK, g_P[S];
+            // ranges cost more in spills than the exposed scalar-cache latency (300 us against 314 / 312 us, kbench).
+            // LOW (S >= 3): a frame's matrix inside its own pass of the frame loop -- three at once, on top of what the
+            // re-derived tap needs, spilled 44 scalars to VGPR lanes (78 v_readlane / v_writelane per step)
+            SRows g_iK, g_P[LOW ? 1 : S];
             sload12(iKp, g_iK);
+            if constexpr (!LOW)
 #pragma unroll
-            for (int f = 0; f < S; ++f) sload12(Pp[f], g_P[f]);
+                for (int f = 0; f < S; ++f) sload12(Pp[f], g_P[f]);
             swait12(g_iK, iK);
+            if constexpr (!LOW)
 #pragma unroll
-            for (int f = 0; f < S; ++f) swait12(g_P[f], Pm[f]);
+                for (int f = 0; f < S; ++f) swait12(g_P[f], Pm[f]);
         }
-#endif
         float r3[3];
         pixel_ray(iK, (float)pxr, (float)gr, r3);     // (float)pxr: one conversion per step instead of a register per item
-#if MDX_TRAIN_DEPTH_LDS
-        const float depth = s_depth[slot_r][lane];
-#else
         const float depth = dph[0];
-#endif
         const float fgr = (float)gr;
         const int sel0 = selp & 15, sel1 = (selp >> 4) & 15, sel2 = (selp >> 8) & 15;
         float gdepth = 0.f;
+        // LOW: the two older coefficient rows come out of the LDS ring (row sr-2: this step's slot, row sr-1: the other);
+        // not at all in waves where no lane selected any frame in the three rows (auto-masked regions)
+        // (read per frame and colour channel right where the vertical sums are formed: 6 values in flight, not 18)
+        bool wave_any = true;
+        if constexpr (LOW) wave_any = __builtin_amdgcn_ballot_w64((selp & 0xfff) != 0) != 0;
+        if (wave_any)
 #pragma unroll
         for (int f = 0; f < S; ++f) {
             const int own = (sel0 == f + 1) | (sel1 == f + 1) | (sel2 == f + 1);
             const int hit = own | dpp_i<0x138>(own) | dpp_i<0x130>(own);
             if (__builtin_amdgcn_ballot_w64(hit != 0 && out_lane) == 0) continue;   // wave-uniform
             const float w0 = sel0 == f + 1 ? wy0 : 0.f, w1 = sel1 == f + 1 ? 1.f : 0.f, w2 = sel2 == f + 1 ? wy2 : 0.f;
-            const float4 sa = s_stash[slot_r][2 * f][lane], sb = s_stash[slot_r][2 * f + 1][lane];
-            const float du[3] = {sa.x, sa.y, sa.z}, dv[3] = {sb.x, sb.y, sb.z};
+            float4 sa, sb;
+            float du[3], dv[3];
+            Tap gt;
+            Corners gc[3];
+            if constexpr (LOW) {
+                // the row's projected position out of the ring; from it the forward's tap (project_point_train's last two
+                // lines and make_tap on the same bits), the corners again, and -- further down, behind the coefficient sums
+                // that cover the loads -- the sampling derivatives
+                const float2 uv = at32(stash_slot(slot_r, f), stash_lane(0u));
+                sa.w = uv.x; sb.w = uv.y;
+                gt = make_tap((div_norm(uv.x, nd.w) - 0.5f) * 2.0f, (div_norm(uv.y, nd.h) - 0.5f) * 2.0f, H, W);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) gc[c] = load_corners(a.src.img[f] + ((size_t)b * 3 + c) * HW, H, W, gt);
+            } else {
+                sa = s_stash[slot_r][2 * f][lane];
+                sb = s_stash[slot_r][2 * f + 1][lane];
+                du[0] = sa.x; du[1] = sa.y; du[2] = sa.z; dv[0] = sb.x; dv[1] = sb.y; dv[2] = sb.z;
+            }
             const bool centre = sel1 == f + 1;
             float gu = 0.f, gv = 0.f;
             // vertical 3-tap sums (own column, registers) of all nine coefficient maps first, then -- behind a
             // scheduling barrier, see the note on DPP operands above -- the horizontal ones (neighbour lanes)
             float vs[3][3], sum3[3][3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c)
+            for (int c = 0; c < 3; ++c) {
+                float ca[3], cb[3];
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    float v = w0 * ch[0][c][k];
-                    v = __builtin_fmaf(w1, ch[1][c][k], v);
-                    vs[c][k] = __builtin_fmaf(w2, ch[2][c][k], v);
+                    ca[k] = LOW ? s_ch[LOW ? (t & 1) : 0][LOW ? c * 3 + k : 0][LOW ? lane : 0] : ch[0][c][k];
+                    cb[k] = LOW ? s_ch[LOW ? ((t + 1) & 1) : 0][LOW ? c * 3 + k : 0][LOW ? lane : 0] : ch[LOW ? 0 : 1][c][k];
                 }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    float v = w0 * ca[k];
+                    v = __builtin_fmaf(w1, cb[k], v);
+                    vs[c][k] = __builtin_fmaf(w2, ch[CN][c][k], v);
+                }
+                if constexpr (LOW) __builtin_amdgcn_sched_barrier(0);
+            }
             __builtin_amdgcn_sched_barrier(0);
             // own + left + right as two DPP-operand adds (an fma cannot take a DPP operand: it cost a v_mov_dpp each);
             // the reflection-pad fold -- column 0's window counts column 1 twice, column W-1's counts W-2 twice -- is
@@ -1044,6 +941,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
                         sum3[c][k] = __builtin_fmaf(from_right(vs[c][k]), ex2, s);
                     }
             }
+            if constexpr (LOW) {
+                const float dy1 = (float)(gt.y0 + 1) - gt.iy, dy0 = gt.iy - (float)gt.y0;
+                const float dx1 = (float)(gt.x0 + 1) - gt.ix, dx0 = gt.ix - (float)gt.x0;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    du[c] = (gc[c].ne - gc[c].nw) * dy1 + (gc[c].se - gc[c].sw) * dy0;
+                    dv[c] = (gc[c].sw - gc[c].nw) * dx1 + (gc[c].se - gc[c].ne) * dx0;
+                }
+            }
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const float xq = xh[0][f][c], yq = yh[0][c];
@@ -1053,9 +959,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
                 gv += gx * dv[c];
             }
             // grid normalisation (2/(W-1)) and grid_sample's un-normalisation ((W-1)/2) cancel
-            gu = (((flp >> (2 * f)) & 1) && out_lane) ? gu : 0.f;
-            gv = (((flp >> (2 * f + 1)) & 1) && out_lane) ? gv : 0.f;
-            const float *Pf = Pm[f];
+            gu = ((LOW ? gt.inx : (((flp >> (2 * f)) & 1) != 0)) && out_lane) ? gu : 0.f;
+            gv = ((LOW ? gt.iny : (((flp >> (2 * f + 1)) & 1) != 0)) && out_lane) ? gv : 0.f;
+            if constexpr (LOW) {
+                SRows g_P;
+                sload12(Pp[f], g_P);
+                swait12(g_P, Pm[0]);
+            }
+            const float *Pf = Pm[LOW ? 0 : f];
             const float X0 = depth * r3[0], X1 = depth * r3[1], X2 = depth * r3[2];
             float z = Pf[8] * X0;
             z = __builtin_fmaf(Pf[9], X1, z);
@@ -1071,26 +982,36 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const float gd = gq[i] * depth;
-                accA[f][i] += gd;
-                accB[f][i] = __builtin_fmaf(fgr, gd, accB[f][i]);
-                accC[f][i] += gq[i];
+                if constexpr (LOW) {
+                    // (the cell's address from a lane id formed here, as for the loss cell: two v_mbcnt, not a register
+                    // held across the loop)
+                    unsigned lid;
+                    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lid));
+                    // read - add - write of the lane's own cells (nobody else touches them): plain LDS traffic; ds_add_f32, the
+                    // unit's atomic path, doubled the launch time at 9 per frame and step
+                    s_acc[f * 9 + i][lid] = s_acc[f * 9 + i][lid] + gd;
+                    s_acc[f * 9 + 3 + i][lid] = __builtin_fmaf(fgr, gd, s_acc[f * 9 + 3 + i][lid]);
+                    s_acc[f * 9 + 6 + i][lid] = s_acc[f * 9 + 6 + i][lid] + gq[i];
+                } else {
+                    accA[f][i] += gd;
+                    accB[f][i] = __builtin_fmaf(fgr, gd, accB[f][i]);
+                    accC[f][i] += gq[i];
+                }
             }
         }
         // depth = 1/(a + b*disp)  ->  d depth / d disp = -b * depth^2
-#if MDX_TRAIN_DEFER_GUP
-        gup_val = gdepth * (-d.disp_b * depth * depth);
-        gup_row = gr;
-#else
         if (out_lane) at32(MDX_LATE(float *, gup) + (size_t)b * HW, (unsigned)(gr * W + pxr)) = gdepth * (-d.disp_b * depth * depth);
-#endif
         MDX_STAMP(3);   // gradient phase
+        }
+        if constexpr (LOW) {
+            // the row formed in this step ages into the ring (over row sr-2, which the gradient phase above was the last to read)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) s_ch[t & 1][c * 3 + k][lane] = ch[CN][c][k];
         }
         }
     }
-#if MDX_TRAIN_DEFER_GUP
-    if constexpr (GRAD)
-        if (gup_row >= 0 && out_lane) at32(MDX_LATE(float *, gup) + (size_t)b * HW, (unsigned)(gup_row * W + pxr)) = gup_val;
-#endif
 #ifdef MDX_TRAIN_STAMPS
     if (lane == 0 && a.stamps) {
 #pragma unroll
@@ -1110,14 +1031,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
     for (int f = 0; f < S; ++f)
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const float sA = wave_sum_dpp_lane63(accA[f][i]);
-            const float sAx = wave_sum_dpp_lane63(accA[f][i] * (float)pxr);
-            const float sB = wave_sum_dpp_lane63(accB[f][i]);
-            const float sC = wave_sum_dpp_lane63(accC[f][i]);
+            const float vA = LOW ? s_acc[LOW ? f * 9 + i : 0][LOW ? lane : 0] : accA[LOW ? 0 : f][i];
+            const float vB = LOW ? s_acc[LOW ? f * 9 + 3 + i : 0][LOW ? lane : 0] : accB[LOW ? 0 : f][i];
+            const float vC = LOW ? s_acc[LOW ? f * 9 + 6 + i : 0][LOW ? lane : 0] : accC[LOW ? 0 : f][i];
+            const float sA = wave_sum_dpp_lane63(vA);
+            const float sAx = wave_sum_dpp_lane63(vA * (float)pxr);
+            const float sB = wave_sum_dpp_lane63(vB);
+            const float sC = wave_sum_dpp_lane63(vC);
             if (lane == 63) {
-#if MDX_TRAIN_SLOAD
                 const float *iK = invK_b;
-#endif
                 float *o = a.partP + (size_t)item * (S * 12) + f * 12 + i * 4;
 #pragma unroll
                 for (int j = 0; j < 3; ++j)
@@ -1125,197 +1047,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRAD ? (S <=
                 o[3] = sC;
             }
         }
-#if MDX_TRAIN_LOSS_LDS
     const double acc_item = wave_sum((double)s_loss[lane]);
-#else
-    const double acc_item = wave_sum((double)acc_reg);
-#endif
     if (lane == 0) a.loss_part[item] = acc_item;
 }
 
-// ---------------------------------------------------------------------------------------------
-// Second pass, ONE launch, fixed summation orders (deterministic):
-//   * transpose of the bilinear upsample (autograd of warp.py:18-20) of every scale below full resolution with an
-//     integer ratio R in {2, 4, 8}: a block owns a tile of TH x TW low-resolution pixels, stages the full-resolution
-//     gradient region their footprints cover in LDS with coalesced 16-byte loads, forms the x / y weights of the
-//     tile once (up_tap: the forward's own tap arithmetic, so borders are exact) and then every pixel sums its
-//     (2R+4)^2 footprint out of LDS (LPO lanes per pixel split the rows, a shuffle tree adds them).  Gathering the
-//     footprints straight from global memory cost ~40 CU-cycles per load instruction (every lane another cache line);
-//   * d(P)[scale][f][b][k] = sum over the items of (scale, b) -- one wave64 per output;
-//   * loss_sum[scale].
-// ---------------------------------------------------------------------------------------------
-struct FinishArgs {
-    const float *gup[MDX_MAX_SCALES];
-    float *gin[MDX_MAX_SCALES];
-    int h[MDX_MAX_SCALES], w[MDX_MAX_SCALES], ratio[MDX_MAX_SCALES], tiles_x[MDX_MAX_SCALES], tiles_y[MDX_MAX_SCALES];
-    int up_first[MDX_MAX_SCALES + 1];   // first block of each scale's upsample job (equal = no job)
-    int B, H, W, nscales, S, ipi;
-    const float *partP;
-    const double *loss_part;
-    float *gP, *loss_sum;
-    unsigned long long *rng;            // optional device {seed, offset}: the step is over, the next one draws new noise
-};
-
-// first / last output index whose bilinear source index scale*(dst+0.5)-0.5 can fall in (i-1, i+1), with a margin of
-// one (the weights decide; the margin only has to cover the rounding of this estimate).  For an even integer ratio R
-// these are R*i - R/2 - 2 and R*i + 3R/2 + 1: a footprint of 2R + 4 taps.
-MDX_DEV int foot_lo(int i, float inv_scale) { return (int)floorf(((float)i - 0.5f) * inv_scale - 0.5f) - 1; }
-MDX_DEV int foot_hi(int i, float inv_scale) { return (int)ceilf(((float)i + 1.5f) * inv_scale - 0.5f) + 1; }
-
-constexpr int FIN_LDS_FLOATS = 44 * 144 + 64 * 20 + 4 * 20;     // largest configuration (R = 8)
-
-template <int R, int TW, int TH, int LPO>
-MDX_DEV void upsample_bwd_tile(const float *__restrict__ gout, int H, int W, float *__restrict__ gin, int h, int w,
-                               int bc, int tile_x, int tile_y, float *lds)
-{
-    constexpr int NT_ = 2 * R + 4;                       // taps per axis
-    constexpr int NR = R * TH + R + 4;                   // region rows
-    constexpr int NC = ((R * TW + R + 4 + 3 + 3) / 4) * 4;   // region columns: + up to 3 for the 16-byte alignment
-    static_assert(NR * NC + TW * NT_ + TH * NT_ <= FIN_LDS_FLOATS, "LDS");
-    static_assert(TW * TH * LPO == NT, "one lane group per pixel");
-    float *s_g = lds, *s_wx = lds + NR * NC, *s_wy = s_wx + TW * NT_;
-    const int tid = threadIdx.x;
-    const int jx0 = tile_x * TW, iy0 = tile_y * TH;
-    const float sy = (float)h / (float)H, sx = (float)w / (float)W;
-    const int ys = R * iy0 - R / 2 - 2;                  // region origin (may lie outside the image: zeros)
-    const int xs = (R * jx0 - R / 2 - 2) & ~3;           // aligned down to 4 columns (arithmetic on negatives is fine: two's complement)
-    const float *g = gout + (size_t)bc * H * W;
-    // ---- stage the region: 16-byte loads where the four columns are inside the image, scalars at its edges ----
-    const bool vec = (W & 3) == 0;
-    for (int e = tid; e < NR * (NC / 4); e += NT) {
-        const int rr = e / (NC / 4), c4 = (e - rr * (NC / 4)) * 4;
-        const int y = ys + rr, x = xs + c4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (y >= 0 && y < H) {
-            if (vec && x >= 0 && x + 3 < W) {
-                v = *reinterpret_cast<const float4 *>(g + (size_t)y * W + x);
-            } else {
-                const float *row = g + (size_t)y * W;
-                v.x = (x >= 0 && x < W) ? row[x] : 0.f;
-                v.y = (x + 1 >= 0 && x + 1 < W) ? row[x + 1] : 0.f;
-                v.z = (x + 2 >= 0 && x + 2 < W) ? row[x + 2] : 0.f;
-                v.w = (x + 3 >= 0 && x + 3 < W) ? row[x + 3] : 0.f;
-            }
-        }
-        *reinterpret_cast<float4 *>(s_g + rr * NC + c4) = v;
-    }
-    // ---- weights of the tile's columns and rows (zero for taps outside the image or not touching the pixel) ----
-    for (int e = tid; e < TW * NT_ + TH * NT_; e += NT) {
-        const bool isx = e < TW * NT_;
-        const int ee = isx ? e : e - TW * NT_;
-        const int p = ee / NT_, t = ee - p * NT_;
-        const int i = (isx ? jx0 : iy0) + p, n_in = isx ? w : h, n_out = isx ? W : H;
-        const int pos = R * i - R / 2 - 2 + t;           // full-resolution index of tap t
-        float wgt = 0.f;
-        if (i < n_in && pos >= 0 && pos < n_out) {
-            const UpTap tp = up_tap(isx ? sx : sy, pos, n_in);
-            wgt = (tp.i0 == i ? tp.l0 : 0.f) + (tp.i1 == i ? tp.l1 : 0.f);
-        }
-        (isx ? s_wx : s_wy)[ee] = wgt;
-    }
-    __syncthreads();
-    // ---- footprint sums ----
-    const int l = tid % LPO, pix = tid / LPO;
-    const int jj = pix % TW, ii = pix / TW;
-    const int c0 = R * (jx0 + jj) - R / 2 - 2 - xs;      // region column of tap 0
-    float wxr[NT_];
-#pragma unroll
-    for (int t = 0; t < NT_; ++t) wxr[t] = s_wx[jj * NT_ + t];
-    float acc = 0.f;
-#pragma unroll
-    for (int it = 0; it < (NT_ + LPO - 1) / LPO; ++it) {
-        const int ty = l + it * LPO;
-        if (ty < NT_) {
-            const float *row = s_g + (R * ii + ty) * NC + c0;
-            float rs = 0.f;
-#pragma unroll
-            for (int t = 0; t < NT_; ++t) rs = __builtin_fmaf(wxr[t], row[t], rs);
-            acc = __builtin_fmaf(s_wy[ii * NT_ + ty], rs, acc);
-        }
-    }
-#pragma unroll
-    for (int m = 1; m < LPO; m <<= 1) acc += __shfl_xor(acc, m, 64);
-    const int jx = jx0 + jj, iy = iy0 + ii;
-    if (l == 0 && jx < w && iy < h) gin[((size_t)bc * h + iy) * w + jx] = acc;
-}
-
-// tile shape by ratio (host and device agree through these)
-static int finish_tw(int r) { return r == 2 ? 64 : (r == 4 ? 32 : 16); }
-static int finish_th(int r) { return 4; }
-#if MDX_TRAIN_LATE_FLAGS
 #undef automask
 #undef premul
 #undef same_res
-#endif
-
-
-__global__ __launch_bounds__(NT) void train_finish_kernel(FinishArgs a)
-{
-    __shared__ __attribute__((aligned(16))) float s_lds[FIN_LDS_FLOATS];
-    const int blk = blockIdx.x;
-    if (blk < a.up_first[MDX_MAX_SCALES]) {
-        const int sc = blk >= a.up_first[3] ? 3 : (blk >= a.up_first[2] ? 2 : (blk >= a.up_first[1] ? 1 : 0));
-        const float *gup = pick(a.gup, sc);
-        float *gin = pick(a.gin, sc);
-        const int h = pick(a.h, sc), w = pick(a.w, sc), r = pick(a.ratio, sc);
-        const int tx_n = pick(a.tiles_x, sc), ty_n = pick(a.tiles_y, sc);
-        const int rel = blk - pick4(a.up_first, sc);
-        const int tile_x = rel % tx_n, tile_y = (rel / tx_n) % ty_n, bc = rel / (tx_n * ty_n);
-        if (r == 2) upsample_bwd_tile<2, 64, 4, 1>(gup, a.H, a.W, gin, h, w, bc, tile_x, tile_y, s_lds);
-        else if (r == 4) upsample_bwd_tile<4, 32, 4, 2>(gup, a.H, a.W, gin, h, w, bc, tile_x, tile_y, s_lds);
-        else upsample_bwd_tile<8, 16, 4, 4>(gup, a.H, a.W, gin, h, w, bc, tile_x, tile_y, s_lds);
-        return;
-    }
-    // reductions.  Loads are issued in groups of four independent ones (a dependent load -> add chain would pay one
-    // memory round trip per element); the order of the additions is fixed.
-    double *s_red = reinterpret_cast<double *>(s_lds);
-    const int rblk = blk - a.up_first[MDX_MAX_SCALES];
-    const int lane = threadIdx.x & 63;
-    const int ngp = a.nscales * a.S * a.B * 12;
-    const int ngp_blocks = (ngp + NT / 64 - 1) / (NT / 64);
-    if (rblk < ngp_blocks) {            // d(P): one wave64 per output, four outputs per block
-        const int i = rblk * (NT / 64) + (threadIdx.x >> 6);
-        if (i >= ngp) return;
-        const int k = i % 12, bb = (i / 12) % a.B, f = (i / (12 * a.B)) % a.S, sc = i / (12 * a.B * a.S);
-        const float *p = a.partP + ((size_t)(sc * a.B + bb) * a.ipi) * (a.S * 12) + f * 12 + k;
-        const size_t stride = (size_t)a.S * 12;
-        double acc = 0.0;
-        for (int t = lane; t < a.ipi; t += 256) {
-            const float v0 = p[(size_t)t * stride];
-            const float v1 = t + 64 < a.ipi ? p[(size_t)(t + 64) * stride] : 0.f;
-            const float v2 = t + 128 < a.ipi ? p[(size_t)(t + 128) * stride] : 0.f;
-            const float v3 = t + 192 < a.ipi ? p[(size_t)(t + 192) * stride] : 0.f;
-            acc += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
-        }
-        acc = wave_sum(acc);
-        if (lane == 0) a.gP[i] = (float)acc;
-    } else {                            // loss_sum[scale]: one block per scale
-        const int sc = rblk - ngp_blocks;
-        if (sc >= a.nscales) return;
-        const double *p = a.loss_part + (size_t)sc * a.B * a.ipi;
-        const int cnt = a.B * a.ipi;
-        double acc = 0.0;
-        for (int t = threadIdx.x; t < cnt; t += 4 * NT) {
-            const double v0 = p[t];
-            const double v1 = t + NT < cnt ? p[t + NT] : 0.0;
-            const double v2 = t + 2 * NT < cnt ? p[t + 2 * NT] : 0.0;
-            const double v3 = t + 3 * NT < cnt ? p[t + 3 * NT] : 0.0;
-            acc += (v0 + v1) + (v2 + v3);
-        }
-        acc = wave_sum(acc);
-        if (lane == 0) s_red[threadIdx.x >> 6] = acc;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            a.loss_sum[sc] = (float)((s_red[0] + s_red[1]) + (s_red[2] + s_red[3]));
-            if (sc == 0 && a.rng) a.rng[1] += 1ull;
-        }
-    }
-}
 
 struct TrainPlan {
     int lev_n[3], lev_r[3], lev_item0[3], lev_row0[3], lev_k0[3];
     int nchunks, nstrips, ncols;
-    size_t items, off_partP, off_gup, total;
+    size_t items, off_partP, off_gup, off_stash, total;
 };
 
 // Chunk schedule of a column of H rows.  rows_per_chunk > 0: uniform chunks of that many rows (tests, sweeps).
@@ -1335,6 +1078,11 @@ static void choose_levels(const mdx_train_desc *d, TrainPlan &p, bool grad)
         r[0] = H >= 160 ? 40 : (H >= 64 ? 24 : 16);
         r[1] = r[0] / 2;
         r[2] = r[1] / 2 > 4 ? r[1] / 2 : 4;
+        if (H >= 256 && grad) {
+            // BASELINE configs[3] (320 x 1024), swept in round 4 (tools/r4_sweep.sh, inside the real step): 4 x 48 + 3 x 24 + 5 x 12
+            // rows 378.5 us against 390.9 us for 40 / 20 / 10 at 0.6 / 0.25 (16 chunks); 64 / 32 / 16: 387.5; 56 / 28 / 14: 397.8
+            r[0] = 48; r[1] = 24; r[2] = 12; f1 = 0.6; f2 = 0.225;
+        }
         if (H >= 160 && H < 256) {
             // re-swept in round 3 for the BASELINE height (tools/sweep_schedule.sh, timing inside the real step): with the
             // gradient phase skipped in auto-masked regions a halo step costs relatively more, and fewer, taller chunks win --
@@ -1385,7 +1133,9 @@ static TrainPlan plan(const mdx_train_desc *d, bool grad)
     p.items = (size_t)p.ncols * p.nchunks;
     p.off_partP = p.items * sizeof(double);
     p.off_gup = p.off_partP + ((p.items * d->S * 12 * sizeof(float) + 15) & ~(size_t)15);
-    p.total = p.off_gup + (size_t)d->nscales * d->B * d->H * d->W * sizeof(float);
+    p.off_stash = p.off_gup + (size_t)d->nscales * d->B * d->H * d->W * sizeof(float);
+    // LOW form (training only): the items' (u, v) rings, 3 rows x S planes of 64 float2
+    p.total = p.off_stash + (train_low(d->S, grad) ? p.items * 3 * (size_t)d->S * 512 : 0);
 #ifdef MDX_TRAIN_STAMPS
     p.total += p.items * 8 * sizeof(unsigned long long);
 #endif
@@ -1404,8 +1154,6 @@ static int validate_train(const mdx_train_desc *d)
     }
     return MDX_OK;
 }
-
-int launch_upsample_bwd(const float *gout, int BC, int H, int W, float *gin, int h, int w, hipStream_t st);
 
 }  // namespace mdx
 
@@ -1474,6 +1222,7 @@ static int train_launch(const mdx_train_desc *d, const float *const *disp, const
     a.target = target; a.ident = ident; a.invK = invK; a.src = *src; a.depth0 = depth0;
     a.loss_part = (double *)workspace;
     a.partP = (float *)((char *)workspace + p.off_partP);
+    a.stash = (float *)((char *)workspace + p.off_stash);
     float *gup_ws = (float *)((char *)workspace + p.off_gup);
     const size_t n = (size_t)d->B * d->H * d->W;
     for (int s = 0; s < d->nscales; ++s) {
@@ -1517,35 +1266,7 @@ static int train_launch(const mdx_train_desc *d, const float *const *disp, const
 #undef MDX_TRAIN_CASE
     if (t && t->stop) (void)hipEventRecord((hipEvent_t)t->stop, st);
     if ((rc = check_launch())) return rc;
-    FinishArgs fa = {};
-    fa.B = d->B; fa.H = d->H; fa.W = d->W; fa.nscales = d->nscales; fa.S = grad ? d->S : 0; fa.ipi = p.nchunks * p.nstrips;
-    fa.partP = a.partP; fa.loss_part = a.loss_part; fa.gP = gP; fa.loss_sum = loss_sum; fa.rng = pre.rng;
-    int nblk = 0;
-    bool separate[MDX_MAX_SCALES] = {false, false, false, false};
-    for (int s = 0; s < MDX_MAX_SCALES; ++s) {
-        fa.up_first[s] = nblk;
-        const int ss = s < d->nscales ? s : 0;
-        fa.gup[s] = a.gup[ss]; fa.gin[s] = grad ? gdisp[ss] : nullptr; fa.h[s] = d->h[ss]; fa.w[s] = d->w[ss];
-        fa.ratio[s] = 2; fa.tiles_x[s] = fa.tiles_y[s] = 1;
-        if (!grad || s >= d->nscales || (d->h[s] == d->H && d->w[s] == d->W)) continue;
-#ifdef MDX_TRAIN_STAMPS
-        if (const char *e = getenv("MDX_FINISH_SKIP")) if (strchr(e, '0' + s)) continue;   // diagnostic: leave a scale out
-#endif
-        // the tiled pass takes the integer ratios 2, 4, 8 (same on both axes); anything else the per-scale kernels
-        const int r = d->W / d->w[s];
-        if (d->W != r * d->w[s] || d->H != r * d->h[s] || (r != 2 && r != 4 && r != 8)) { separate[s] = true; continue; }
-        fa.ratio[s] = r;
-        fa.tiles_x[s] = (d->w[s] + finish_tw(r) - 1) / finish_tw(r);
-        fa.tiles_y[s] = (d->h[s] + finish_th(r) - 1) / finish_th(r);
-        nblk += fa.tiles_x[s] * fa.tiles_y[s] * d->B;
-    }
-    fa.up_first[MDX_MAX_SCALES] = nblk;
-    const int ngp_blocks = (d->nscales * fa.S * d->B * 12 + NT / 64 - 1) / (NT / 64);
-    hipLaunchKernelGGL(train_finish_kernel, dim3(nblk + ngp_blocks + d->nscales), dim3(NT), 0, st, fa);
-    if ((rc = check_launch())) return rc;
-    for (int s = 0; s < d->nscales; ++s)
-        if (separate[s] && (rc = launch_upsample_bwd(a.gup[s], d->B, d->H, d->W, gdisp[s], d->h[s], d->w[s], st))) return rc;
-    return MDX_OK;
+    return launch_train_finish(d, grad, p.nchunks * p.nstrips, a.partP, a.loss_part, a.gup, gdisp, gP, loss_sum, pre.rng, st);
 }
 
 MDX_EXPORT int mdx_photometric_train(const mdx_train_desc *d, const float *const *disp, const float *target,

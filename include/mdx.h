@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MDX_VERSION 300
+#define MDX_VERSION 400
 #define MDX_MAX_SRC 4
 #define MDX_MAX_SCALES 4
 
@@ -202,12 +202,14 @@ int mdx_photometric_train_pre(const mdx_train_desc *d, const float *const *disp,
 
 /* Edge-aware smoothness   replaces model_loss.py:77-88,112-115 (processor.py:208).
  * disp [B,1,h,w], color [B,3,h,w] -> loss [1]; gdisp (optional) = d loss / d disp for unit upstream.
- * normalize = 1: SmoothLoss (disp / (mean_HW(disp) + 1e-7) first); 0: EdgeAwareSmooth on disp as given. */
+ * normalize = 1: SmoothLoss (disp / (mean_HW(disp) + 1e-7) first); 0: EdgeAwareSmooth on disp as given.
+ * Two launches (MDX_VERSION 400; four before): a main pass on the disparity as given + a finishing pass that forms the
+ * per-image mean from the main pass's partials. */
 size_t mdx_smooth_workspace_bytes(int B, int h, int w);
 int mdx_smooth_loss(int B, int h, int w, const float *disp, const float *color, int normalize, float *loss,
                     float *gdisp, void *workspace, size_t workspace_bytes, void *stream);
 
-/* The same for every scale of a step, each pass launched once for all scales (the scale loop of processor.py:208):
+/* The same for every scale of a step, both passes launched once for all scales (the scale loop of processor.py:208):
  * h, w, disp, color, gdisp: HOST arrays of nscales entries (gdisp NULL or all entries given); loss [nscales]. */
 size_t mdx_smooth_multi_workspace_bytes(int nscales, int B, const int32_t *h, const int32_t *w);
 int mdx_smooth_loss_multi(int nscales, int B, const int32_t *h, const int32_t *w, const float *const *disp,

@@ -257,8 +257,8 @@ def test_abi_reports_misuse_on_gpu(G):
 def test_ssim_module_backward_vs_autograd(G, saturate):
     """model_loss.SSIM alone is differentiable (mdx_ssim_bwd): gradients wrt BOTH images for a random per-channel upstream
     against autograd of the reference formula (model_loss.py:28-41) evaluated in float64 -- no 0.85/3 factor, no L1 term.
-    saturate: y = 1 - x over smooth fields drives (1 - SSIM)/2 to the clamp's upper end over whole regions (gradient
-    exactly zero there), and x = y regions sit on its lower end."""
+    saturate: y = 1 - x over smooth fields drives (1 - SSIM)/2 towards the clamp's upper end over whole regions, and x = y
+    regions sit on its lower end (value 0 up to rounding, gradient 0)."""
     import sys, os
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import torch_composite as tc
@@ -281,10 +281,16 @@ def test_ssim_module_backward_vs_autograd(G, saturate):
     yr = torch.from_numpy(y).double().requires_grad_(True)
     ref = tc.ssim(xr, yr)
     ref.backward(torch.from_numpy(up).double())
-    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), atol=2e-5)
+    # (the value is pinned bit for bit elsewhere; float32 against this float64 evaluation: the quotient's cancellation)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), atol=1e-3)
     if saturate:
-        sat = (ref.detach() >= 1.0).float().mean()
-        assert float(sat) > 0.2, "the case does not saturate the clamp (%.3f)" % float(sat)
+        # (1 - SSIM) / 2 lies in [0, 1] mathematically: the clamp only ever acts at rounding level -- at its lower end where the
+        # images are identical (SSIM = 1, a maximum: zero gradient), near its upper end where they are anti-correlated
+        lo = (ref.detach()[..., 2:W // 3 - 2] <= 1e-12).float().mean()
+        hi = ref.detach()[..., W // 3 + 2:].mean()
+        assert float(lo) > 0.99 and float(hi) > 0.5, "the case reaches neither end of the clamp (%.3f, %.3f)" % (float(lo), float(hi))
+        gmax = float(xt.grad.abs().max())
+        assert float(xt.grad[..., 2:W // 3 - 2].abs().max()) <= 1e-3 * gmax, "gradient where the images are identical"
     # pixels whose float32 value sits within rounding of a clamp end may take the other branch than float64: compare away
     # from the ends' float32 neighbourhood by masking the (dilated) set of windows that are that close
     raw = ref.detach().numpy()

@@ -18,7 +18,6 @@ import os
 import sys
 
 SIMDS, CLK_GHZ = 1024, 2.4
-RATE_3WAVES = 0.314          # plain VALU wave-instructions per SIMD-cycle at 3 waves/SIMD (profiles/r02_micro_dpp_rate.txt)
 
 
 def main():
@@ -41,7 +40,7 @@ def main():
     import build as B
     out = {"lib_sha16": hashlib.sha256(open(so, "rb").read()).hexdigest()[:16], "source_sha16": B.source_sha16(), "shape": shape,
            "source": ("tools/pmc_bench.sh: rocprofv3 --pmc over `python bench.py` itself (the timed step's own launches and "
-                      "tensors), means per launch" if "pmc_bench" in src else
+                      "tensors), means per launch" if ("pmc_bench" in src or "pmc_c" in src) else
                       "tools/pmc_train.sh (tools/kbench.py --what train), means per launch"), "kernels": {}}
     regs = {}      # registers / occupancy: tools/kernel_resources.py (the trace's VGPR_Count field is not the ISA's count)
     for k, d in agg.items():
@@ -53,8 +52,6 @@ def main():
             e["traffic_bytes_raw"] = (m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024
         if "SQ_INSTS_VALU" in m:
             e["valu_wave_insts"] = m["SQ_INSTS_VALU"]
-            e["valu_issue_us"] = m["SQ_INSTS_VALU"] / SIMDS * 2.0 / (CLK_GHZ * 1e3)        # 2 cycles per wave64 VALU op
-            e["valu_issue_us_at_3_waves"] = m["SQ_INSTS_VALU"] / SIMDS / RATE_3WAVES / (CLK_GHZ * 1e3)
         if "SQ_ACTIVE_INST_VALU" in m:
             # SQ_ACTIVE_INST_VALU counts, in units of 4 cycles, the time waves spend with a VALU instruction executing: summed
             # over the waves of a SIMD it is the time that SIMD's vector ALU is occupied (a wave64 instruction holds it 4 cycles)
