@@ -424,7 +424,7 @@ def main():
                     help="trainer loop only with decoded frames (skip the second run fed with ready 192x640 entries)")
     ap.add_argument("--workers", type=int, default=0,
                     help="DataLoader workers of the trainer-loop measurement (0 = sized from the host share of this rank: "
-                         "12 for fp32, 16 with --amp bf16 whose step consumes ~900 samples/s)")
+                         "12 for fp32, up to 24 with --amp bf16 whose step consumes ~900 samples/s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--selftest-launcher", action="store_true", help=argparse.SUPPRESS)
@@ -451,8 +451,17 @@ def main():
     torch.cuda.set_device(local)
     device = "cuda:%d" % local
     if args.workers <= 0:
-        share = max(2, len(os.sched_getaffinity(0)) // max(1, min(world, torch.cuda.device_count())))
-        args.workers = max(2, min(16 if args.amp == "bf16" else 12, share - 2))
+        cores = len(os.sched_getaffinity(0))
+        try:                                   # a container's CPU quota (cgroup v2) counts, not the host's core count
+            quota = open("/sys/fs/cgroup/cpu.max").read().split()
+            if quota[0] != "max":
+                cores = max(1, min(cores, int(round(int(quota[0]) / int(quota[1])))))
+        except (OSError, ValueError, IndexError):
+            pass
+        share = max(2, cores // max(1, min(world, torch.cuda.device_count())))
+        # bf16 networks consume ~900 samples/s: a few workers more than cores cover the decoders' waits (one set on 16 cores:
+        # 1117 samples/s with 16 workers, 1214 with 24 -- profiles/r04_loader_8ranks.json)
+        args.workers = max(2, min(24, share + share // 2) if args.amp == "bf16" else min(12, share - 2))
     backend = os.environ.get("MDX_DIST_BACKEND", "nccl")       # "nccl" is RCCL on ROCm; "gloo" only to rehearse
     if world > 1 or args.dist:
         kw = {}

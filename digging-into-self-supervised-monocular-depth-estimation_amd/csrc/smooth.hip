@@ -26,6 +26,8 @@ MDX_DEV float edge_weight(const float *__restrict__ c0, size_t hw, size_t i, siz
     return __expf(-g);      // hardware exponential: the smoothness term carries a 1e-4 tolerance, no pinned order
 }
 
+constexpr int APPLY_PIX = 8 * NT;      // pixels of one image per block of the finishing pass
+
 MDX_DEV float sgn(float a, float b) { return (a > b) ? 1.f : ((a < b) ? -1.f : 0.f); }
 
 // the block's four partial sums -> part[(b * nbx + bx) * 4 ..]
@@ -159,7 +161,7 @@ struct SmoothJobs {
     int nscales, B, normalize;
     int h[MDX_MAX_SCALES], w[MDX_MAX_SCALES];
     int nblk[MDX_MAX_SCALES];         // main-pass blocks per image (vec: blocks of NT quads)
-    int ngb[MDX_MAX_SCALES];          // finishing-pass blocks per image (NT pixels each)
+    int ngb[MDX_MAX_SCALES];          // finishing-pass blocks per image (APPLY_PIX pixels each)
     int vec[MDX_MAX_SCALES];          // 1: four pixels per thread (w % 4 == 0, 16-byte aligned planes)
     int first_main[MDX_MAX_SCALES + 1], first_apply[MDX_MAX_SCALES + 1];   // block ranges
     const float *disp[MDX_MAX_SCALES], *color[MDX_MAX_SCALES];
@@ -205,8 +207,9 @@ MDX_DEV void image_totals(const double *__restrict__ part_b, int nblk, double (&
     for (int c = 0; c < 4; ++c) t[c] = __shfl(wave_sum(a[c]), 0, 64);
 }
 
-// Finishing pass.  Blocks [0, first_apply[MAX]): gdisp = G' / m - dot / (m^2 * h*w) in place, NT pixels of one image per
-// block (every wave re-reduces the image's partials for itself: no LDS, no barrier).  The last `nscales` blocks: the loss of
+// Finishing pass.  Blocks [0, first_apply[MAX]): gdisp = G' / m - dot / (m^2 * h*w) in place, APPLY_PIX pixels of one image
+// per block (every wave re-reduces the image's partials for itself -- no LDS, no barrier -- which is why a block takes 8
+// pixels per thread: with one pixel per thread the re-reduction was most of the pass, 14.9 us).  The last `nscales` blocks: the loss of
 // one scale each -- wave k takes images k, k+4, ..., the four wave totals are added in a fixed order.
 __global__ __launch_bounds__(NT) void smooth_multi_finish_kernel(SmoothJobs j)
 {
@@ -217,11 +220,27 @@ __global__ __launch_bounds__(NT) void smooth_multi_finish_kernel(SmoothJobs j)
         const int b = rel / ngb, chunk = rel - b * ngb;
         double t[4];
         image_totals(spick(j.part, s) + (size_t)b * nblk * 4, nblk, t);
-        const unsigned i = (unsigned)chunk * NT + threadIdx.x;
-        if (i >= (unsigned)hw) return;
         const double m = (double)((float)(t[0] / (double)hw) + 1e-7f);      // mean + 1e-7 as the reference forms it (float32)
+        const float inv_am = (float)(1.0 / fabs(m)), shift = (float)((m < 0.0 ? -t[3] : t[3]) / (m * m * (double)hw));
         float *G = spick(j.gdisp, s) + (size_t)b * hw;
-        G[i] = (float)((double)G[i] / fabs(m) - (m < 0.0 ? -t[3] : t[3]) / (m * m * (double)hw));
+        const unsigned base = (unsigned)chunk * APPLY_PIX;
+        if (spick(j.vec, s)) {              // hw % 4 == 0, 16-byte aligned planes: two float4 per thread
+#pragma unroll
+            for (int r = 0; r < APPLY_PIX / (4 * NT); ++r) {
+                const unsigned i = base + ((unsigned)r * NT + threadIdx.x) * 4u;
+                if (i < (unsigned)hw) {
+                    float4 g = *reinterpret_cast<float4 *>(G + i);
+                    g.x = g.x * inv_am - shift; g.y = g.y * inv_am - shift; g.z = g.z * inv_am - shift; g.w = g.w * inv_am - shift;
+                    *reinterpret_cast<float4 *>(G + i) = g;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < APPLY_PIX / NT; ++r) {
+                const unsigned i = base + (unsigned)r * NT + threadIdx.x;
+                if (i < (unsigned)hw) G[i] = G[i] * inv_am - shift;
+            }
+        }
         return;
     }
     __shared__ double s_red[NT / 64];
@@ -245,6 +264,7 @@ __global__ __launch_bounds__(NT) void smooth_multi_finish_kernel(SmoothJobs j)
 }
 
 static size_t smooth_nblk(int h, int w) { return ((size_t)h * w + NT - 1) / NT; }
+static size_t smooth_napply(int h, int w) { return ((size_t)h * w + APPLY_PIX - 1) / APPLY_PIX; }
 
 }  // namespace mdx
 
@@ -290,7 +310,7 @@ MDX_EXPORT int mdx_smooth_loss_multi(int nscales, int B, const int32_t *h, const
         j.gdisp[s] = gdisp ? gdisp[ss] : nullptr;
         j.vec[s] = (w[ss] % 4 == 0) && aligned(disp[ss], 16) && aligned(color[ss], 16) && (!gdisp || aligned(gdisp[ss], 16));
         j.nblk[s] = j.vec[s] ? (int)(((size_t)h[ss] * (w[ss] / 4) + NT - 1) / NT) : (int)smooth_nblk(h[ss], w[ss]);
-        j.ngb[s] = (int)smooth_nblk(h[ss], w[ss]);
+        j.ngb[s] = (int)smooth_napply(h[ss], w[ss]);
         if (s >= nscales) { j.part[s] = j.part[0]; continue; }
         if ((j.gdisp[s] != nullptr) != (j.gdisp[0] != nullptr)) return MDX_ERR_NULL_POINTER;   // all or none
         j.part[s] = (double *)ws;

@@ -177,7 +177,7 @@ def test_kitti_tree_training_and_eigen_style_evaluation(G, tmp_path):
     assert 0 <= res["a1"] <= res["a2"] <= res["a3"] <= 1
 
 
-def _trainer_losses(graph, automask=False, noise="device", n=6, lr_change_at=4, amp="none", channels_last=False):
+def _trainer_losses(graph, automask=False, noise="device", n=6, lr_change_at=4, amp="none", channels_last=False, batches=None):
     import importlib
     bench = importlib.import_module("bench")
     from model_train import trainer
@@ -187,7 +187,9 @@ def _trainer_losses(graph, automask=False, noise="device", n=6, lr_change_at=4, 
     opt.noise, opt.channels_last = noise, channels_last
     tr = trainer(opt)
     tr.setting.set_train()
-    batches = list(tr.setting.train_dataloader)[:n]
+    if batches is None:
+        batches = list(tr.setting.train_dataloader)[:n]
+    tr.last_batches = batches
     torch.manual_seed(1)
     losses = []
     for i, b in enumerate(batches):
@@ -280,7 +282,9 @@ def test_synchronous_collectives_refuse_capture_on_gpu(G, rccl_group_of_one):
     x = torch.ones(4, device=G.DEV)
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
-    for call in (lambda: parallel.mean_over_ranks([1.0, 2.0], G.DEV), lambda: parallel.broadcast_state([torch.nn.Linear(2, 2).to(G.DEV)])):
+    lin = torch.nn.Linear(2, 2).to(G.DEV)                  # (built outside: an upload inside a capture is its own error)
+    torch.cuda.synchronize()
+    for call in (lambda: parallel.mean_over_ranks([1.0, 2.0], G.DEV), lambda: parallel.broadcast_state([lin])):
         g = torch.cuda.CUDAGraph()
         with pytest.raises(RuntimeError, match="synchronous collective"):
             with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
@@ -292,7 +296,7 @@ def test_synchronous_collectives_refuse_capture_on_gpu(G, rccl_group_of_one):
     assert not parallel.capturing()
     # outside a capture the same calls work, over RCCL
     assert parallel.mean_over_ranks([1.0, 2.0], G.DEV) == [1.0, 2.0]
-    parallel.broadcast_state([torch.nn.Linear(2, 2).to(G.DEV)])
+    parallel.broadcast_state([lin])
     y = torch.ones(3, device=G.DEV)
     rccl_group_of_one.all_reduce(y)
     torch.cuda.synchronize()
@@ -311,7 +315,8 @@ def test_trainer_channels_last_data_parallel_fused_adam(G):
     dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % bench.free_port(), rank=0, world_size=1,
                             device_id=torch.device(torch.cuda.current_device()))
     try:
-        dp, _, tr_d = _trainer_losses(False, channels_last=True)
+        # the same batches (a process group brings a DistributedSampler: another order)
+        dp, _, tr_d = _trainer_losses(False, channels_last=True, batches=tr_p.last_batches)
         sync = tr_d.setting.sync
         assert sync is not None
         assert all(p.grad.stride() == p.stride() and p.grad.data_ptr() == sync.flat.data_ptr() + 4 * sync.offsets[id(p)]
