@@ -21,7 +21,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include "photo_train.hpp"
+#include "photo_train_math.hpp"
 
 namespace mdx {
 
@@ -77,264 +77,6 @@ struct TrainArgs {
 #endif
 
 
-template <int CTRL> MDX_DEV float dpp_f(float v)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
-}
-template <int CTRL> MDX_DEV int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
-// value held by the lane to the left / right (0 at the ends of the wave).  EVERY lane must be active.
-MDX_DEV float from_left(float v) { return dpp_f<0x138>(v); }    // wave_shr:1
-MDX_DEV float from_right(float v) { return dpp_f<0x130>(v); }   // wave_shl:1
-
-// AvgPool2d(3,1) at this lane's column for N independent quantities at once; a[i][j] = quantity i at history row j.
-// Per quantity the nine taps are summed row-major, sequentially, then truly divided by 9 -- pool9()'s order, with
-// the side columns read from the neighbour lanes.  The N chains advance in lock step: a DPP instruction that reads a
-// register written by one of the two preceding VALU instructions costs wait states (s_nop), and a VALU instruction
-// that consumes its predecessor's result issues at half rate (profiles/r02_micro_valu_dep.txt); with N >= 3 chains
-// interleaved neither happens.
-template <int N> MDX_DEV void pool3_n(const float (&a)[N][3], float (&out)[N])
-{
-    float s[N];
-#pragma unroll
-    for (int i = 0; i < N; ++i) s[i] = from_left(a[i][0]) + a[i][0];
-#pragma unroll
-    for (int i = 0; i < N; ++i) s[i] = s[i] + from_right(a[i][0]);
-#pragma unroll
-    for (int j = 1; j < 3; ++j) {
-#pragma unroll
-        for (int i = 0; i < N; ++i) s[i] = s[i] + from_left(a[i][j]);
-#pragma unroll
-        for (int i = 0; i < N; ++i) s[i] = s[i] + a[i][j];
-#pragma unroll
-        for (int i = 0; i < N; ++i) s[i] = s[i] + from_right(a[i][j]);
-    }
-#pragma unroll
-    for (int i = 0; i < N; ++i) out[i] = div9(s[i]);
-}
-
-// n / d and 1 / d together.  The correctly rounded float32 quotient as the compiler expands `n / d` for gfx950 is
-//   s = div_scale(...); r0 = rcp(d_s); e0 = fma(-d_s, r0, 1); r1 = fma(e0, r0, r0); q0 = n_s * r1;
-//   e1 = fma(-d_s, q0, n_s); q1 = fma(e1, r1, q0); e2 = fma(-d_s, q1, n_s); q = div_fixup(div_fmas(e2, r1, q1))
-// (11 instructions), where div_scale / div_fmas / div_fixup only act when an operand or the quotient is near the ends
-// of the exponent range (|d| or |n / d| beyond 2^+-96, subnormals, infinities).  Written out without those three -- the
-// SAME operations on the same values whenever no scaling applies, hence the same bits -- the sequence is 8 instructions and
-// leaves r1 = 1/d to 1 ulp, which the gradient coefficients need anyway (they used a second rcp + Newton step).
-// Domain here: d = B1 * B2 >= C1 * C2 = 9e-8, |n| = |A1 * A2| is 0 or >= 1e-4 * 2^-34 for colours in [0, 255]
-// (tools/check_fastdiv.hip compares 2^32 pairs of that domain against `/` on the GPU: profiles/r03_fastdiv_check.txt).
-struct QuotRcp { float q, r; };
-MDX_DEV QuotRcp quot_rcp(float n, float d)
-{
-    const float r0 = __builtin_amdgcn_rcpf(d);
-    const float e0 = __builtin_fmaf(-d, r0, 1.0f);
-    const float r1 = __builtin_fmaf(e0, r0, r0);
-    const float q0 = n * r1;
-    const float e1 = __builtin_fmaf(-d, q0, n);
-    const float q1 = __builtin_fmaf(e1, r1, q0);
-    const float e2 = __builtin_fmaf(-d, q1, n);
-    QuotRcp o;
-    o.q = __builtin_fmaf(e2, r1, q1);
-    o.r = r1;
-    return o;
-}
-
-// the target's window statistics as the SSIM quotient consumes them: sig_y = pool(y*y) - mu_y^2 (ssim_raw()'s own
-// subtraction, formed here once per pixel -- or once per STEP by photo_prologue.hip)
-struct TStat { float mu, mu2, sig_y; };
-
-// SSIM of one colour channel of one frame in two halves.  The VALUE now: ssim_raw()'s operations in ssim_raw()'s order
-// (bit-exact), keeping the intermediates the gradient needs.  The COEFFICIENT triplet of SURVEY appendix A.1 later, only in
-// waves where the frame can still be some lane's arg-min (in auto-masked regions never): it re-uses those intermediates
-// and quot_rcp's refined reciprocal (gradients carry a 1e-4 tolerance, not bit-exactness).
-struct SsimMid { float A1, A2, B1, B2, q, inv_d, mu_x, raw; };
-
-// The value for the THREE colour channels of a frame in lock step: every operation of ssim_raw() (mdx_device.hpp) for channel
-// 0, 1, 2 in turn (the same operations on the same values: the same bits), the quotient by quot_rcp()'s sequence.  A VALU instruction that reads its predecessor's result
-// costs ~2 extra cycles which other waves do not fill (profiles/r02_micro_valu_dep.txt); one channel's value is a chain of
-// ~25 such instructions (the 8 of the quotient back to back), three channels interleaved have none.  The statements are
-// written round-robin and pinned with MDX_LOCKSTEP (an empty asm the three values pass through): the scheduler, which
-// orders for register pressure here, would otherwise put each chain back together.
-#define MDX_LOCKSTEP(a, b, c) asm volatile("" : "+v"(a), "+v"(b), "+v"(c))
-MDX_DEV void ssim_value_mid3(const float (&o)[3][3], const TStat (&t)[3], SsimMid (&m)[3], float (&val)[3])
-{
-    float mxx[3], mxy[3], sig_x[3], sig_xy[3], a[3], n[3], d[3], r0[3], e0[3], r1[3], q0[3], e1[3], q1[3], e2[3];
-#define MDX_EACH(stmt) { const int c = 0; stmt; } { const int c = 1; stmt; } { const int c = 2; stmt; }
-    MDX_EACH(mxx[c] = o[c][0] * o[c][0])
-    MDX_EACH(mxy[c] = o[c][0] * t[c].mu)
-    MDX_EACH(sig_x[c] = o[c][1] - mxx[c])
-    MDX_EACH(sig_xy[c] = o[c][2] - mxy[c])
-    MDX_EACH(a[c] = 2.0f * o[c][0])
-    MDX_EACH(a[c] = a[c] * t[c].mu)
-    MDX_LOCKSTEP(a[0], a[1], a[2]);
-    MDX_EACH(m[c].A1 = a[c] + MDX_C1)
-    MDX_EACH(m[c].A2 = 2.0f * sig_xy[c])
-    MDX_EACH(m[c].A2 = m[c].A2 + MDX_C2)
-    MDX_EACH(m[c].B1 = (mxx[c] + t[c].mu2))
-    MDX_EACH(m[c].B1 = m[c].B1 + MDX_C1)
-    MDX_EACH(m[c].B2 = (sig_x[c] + t[c].sig_y))
-    MDX_EACH(m[c].B2 = m[c].B2 + MDX_C2)
-    MDX_EACH(n[c] = m[c].A1 * m[c].A2)
-    MDX_EACH(d[c] = m[c].B1 * m[c].B2)
-    MDX_LOCKSTEP(d[0], d[1], d[2]);
-    // quot_rcp(n, d), three at a time
-    MDX_EACH(r0[c] = __builtin_amdgcn_rcpf(d[c]))
-    MDX_LOCKSTEP(r0[0], r0[1], r0[2]);
-    MDX_EACH(e0[c] = __builtin_fmaf(-d[c], r0[c], 1.0f))
-    MDX_LOCKSTEP(e0[0], e0[1], e0[2]);
-    MDX_EACH(r1[c] = __builtin_fmaf(e0[c], r0[c], r0[c]))
-    MDX_LOCKSTEP(r1[0], r1[1], r1[2]);
-    MDX_EACH(q0[c] = n[c] * r1[c])
-    MDX_LOCKSTEP(q0[0], q0[1], q0[2]);
-    MDX_EACH(e1[c] = __builtin_fmaf(-d[c], q0[c], n[c]))
-    MDX_LOCKSTEP(e1[0], e1[1], e1[2]);
-    MDX_EACH(q1[c] = __builtin_fmaf(e1[c], r1[c], q0[c]))
-    MDX_LOCKSTEP(q1[0], q1[1], q1[2]);
-    MDX_EACH(e2[c] = __builtin_fmaf(-d[c], q1[c], n[c]))
-    MDX_LOCKSTEP(e2[0], e2[1], e2[2]);
-    MDX_EACH(m[c].q = __builtin_fmaf(e2[c], r1[c], q1[c]))
-    MDX_LOCKSTEP(m[0].q, m[1].q, m[2].q);
-    MDX_EACH(m[c].inv_d = r1[c])
-    MDX_EACH(m[c].mu_x = o[c][0])
-    MDX_EACH(m[c].raw = 1.0f - m[c].q)
-    MDX_LOCKSTEP(m[0].raw, m[1].raw, m[2].raw);
-    MDX_EACH(m[c].raw = m[c].raw / 2.0f)
-    MDX_LOCKSTEP(m[0].raw, m[1].raw, m[2].raw);
-    MDX_EACH(val[c] = clamp01(m[c].raw))
-#undef MDX_EACH
-}
-
-// gradient-only arithmetic may fuse multiply-adds (tolerance 1e-4; the VALUES stay unfused: -ffp-contract=off)
-#define MDX_GRAD_FP _Pragma("clang fp contract(fast)")
-MDX_DEV SsimGrad ssim_coef_mid(const SsimMid &m, const TStat &t, float gscale)
-{
-    MDX_GRAD_FP
-    const float Ln = -0.5f * m.inv_d, Ld = 0.5f * m.q * m.inv_d;
-    const float dA1 = Ln * m.A2, dA2 = Ln * m.A1, dB1 = Ld * m.B2, dB2 = Ld * m.B1;
-    const bool pass = m.raw >= 0.f && m.raw <= 1.f;   // clamp passes the gradient on the closed interval
-    const float gs = pass ? gscale : 0.f;
-    SsimGrad g;
-    g.alpha = gs * 2.0f * (t.mu * (dA1 - dA2) + m.mu_x * (dB1 - dB2));
-    g.beta = gs * dB2;
-    g.gamma = gs * 2.0f * dA2;
-    return g;
-}
-
-// ---- the geometry's divisions with the same written-out sequence ----
-// depth = 1 / sd, and u = q0 / z, v = q1 / z sharing ONE refined reciprocal of z (22 -> 11 instructions per frame).
-// Bit-equal to the IEEE `/` whenever no operand needs div_scale's rescaling; a zero, subnormal, infinite or NaN
-// divisor anywhere in the wave sends the whole wave through `/` (one v_cmp_class + a scalar branch that is never taken
-// on real data: z = q2 + 1e-7 is 0 or >= 2^-47 in magnitude).
-MDX_DEV bool wave_all_normal(float v)
-{
-    return __builtin_amdgcn_ballot_w64(__builtin_amdgcn_classf(v, 0x2F7)) == 0;   // anything but +-normal (classf: the float form)
-}
-MDX_DEV float refined_rcp(float d)
-{
-    const float r0 = __builtin_amdgcn_rcpf(d);
-    return __builtin_fmaf(__builtin_fmaf(-d, r0, 1.0f), r0, r0);
-}
-MDX_DEV float quot_with(float n, float d, float r1)
-{
-    const float q0 = n * r1;
-    const float q1 = __builtin_fmaf(__builtin_fmaf(-d, q0, n), r1, q0);
-    return __builtin_fmaf(__builtin_fmaf(-d, q1, n), r1, q1);
-}
-
-// project_point() (mdx_device.hpp) with the shared-reciprocal divisions
-MDX_DEV Proj project_point_train(const float *__restrict__ P, float X0, float X1, float X2, const Norm2 &nd, float eps)
-{
-    float q[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        float t = P[i * 4 + 0] * X0;
-        t = __builtin_fmaf(P[i * 4 + 1], X1, t);
-        t = __builtin_fmaf(P[i * 4 + 2], X2, t);
-        q[i] = __builtin_fmaf(P[i * 4 + 3], 1.0f, t);
-    }
-    Proj p;
-    p.z = q[2] + eps;
-    if (wave_all_normal(p.z)) {
-        const float r1 = refined_rcp(p.z);
-        p.u = quot_with(q[0], p.z, r1);
-        p.v = quot_with(q[1], p.z, r1);
-    } else {
-        p.u = q[0] / p.z;
-        p.v = q[1] / p.z;
-    }
-    // u / (W-1), v / (H-1): div_norm() picks per LANE between the verified 3-instruction constant division and the IEEE
-    // divide (a select: both run).  A per-WAVE choice was measured in round 3 and is not faster.
-    p.gx = (div_norm(p.u, nd.w) - 0.5f) * 2.0f;
-    p.gy = (div_norm(p.v, nd.h) - 0.5f) * 2.0f;
-    return p;
-}
-
-// geom_from_disp() (photo_common.hpp) with the written-out reciprocal
-MDX_DEV PixelGeom geom_from_disp_train(const mdx_desc &d, float up, const float *__restrict__ invK_b, int px, int py)
-{
-    PixelGeom g;
-    const float sd = scaled_disp(up, d.disp_a, d.disp_b);
-    if (wave_all_normal(sd)) g.depth = quot_with(1.0f, sd, refined_rcp(sd));
-    else g.depth = 1.0f / sd;
-    pixel_ray(invK_b, (float)px, (float)py, g.r);
-    g.X0 = g.depth * g.r[0];
-    g.X1 = g.depth * g.r[1];
-    g.X2 = g.depth * g.r[2];
-    return g;
-}
-
-// ---- the item's 3x4 matrices as TRANSIENT scalars ----
-// P (S x 12) and invK (12) are wave-uniform.  Held in scalar registers for the whole item they take 36 of the ~100
-// SGPRs; with the row pointers of a step on top the allocator spilled 61 values to VGPR lanes and paid ~90
-// v_readlane / v_writelane (VALU issue slots, plus hazard s_nops) per step.  They are re-read through the scalar cache
-// where they are used (s_load_dwordx4 x3 per matrix, scalar unit, no VALU slot) so that they are dead in between:
-// 61 -> 41 spilled SGPRs, 120 -> 45 v_readlane, 165 -> 116 s_nop cycles in the kernel, -1.5 % time.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
-typedef unsigned u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
-struct SRows {
-    f32x4 a, b, c;
-};
-static __device__ __forceinline__ const float *uniform_ptr(const float *p)
-{
-    const unsigned long long v = (unsigned long long)p;
-    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
-    return (const float *)(((unsigned long long)hi << 32) | lo);
-}
-static __device__ __forceinline__ void sload12(const float *p, SRows &m)
-{
-    asm volatile("s_load_dwordx4 %0, %3, 0x0\n\ts_load_dwordx4 %1, %3, 0x10\n\ts_load_dwordx4 %2, %3, 0x20"
-                 : "=&s"(m.a), "=&s"(m.b), "=&s"(m.c)
-                 : "s"(p));
-}
-static __device__ __forceinline__ void swait12(SRows &m, float *o)     // the loads above have landed; o = the 12 floats
-{
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(m.a), "+s"(m.b), "+s"(m.c));
-    o[0] = m.a.x; o[1] = m.a.y; o[2] = m.a.z; o[3] = m.a.w;
-    o[4] = m.b.x; o[5] = m.b.y; o[6] = m.b.z; o[7] = m.b.w;
-    o[8] = m.c.x; o[9] = m.c.y; o[10] = m.c.z; o[11] = m.c.w;
-}
-
-// SSIM value alone (the no-gradient form of the kernel): ssim_raw()'s operation order, bit-equal to ssim_both().val
-MDX_DEV float ssim_val(const SsimTerms &s, const TStat &t)
-{
-    const float mxx = s.mu_x * s.mu_x;
-    const float mxy = s.mu_x * t.mu;
-    const float sig_x = s.ex2 - mxx;
-    const float sig_y = t.sig_y;
-    const float sig_xy = s.exy - mxy;
-    float a = 2.0f * s.mu_x;
-    a = a * t.mu;
-    const float A1 = a + MDX_C1;
-    float A2 = 2.0f * sig_xy;
-    A2 = A2 + MDX_C2;
-    const float n = A1 * A2;
-    const float B1 = (mxx + t.mu2) + MDX_C1;
-    const float B2 = (sig_x + sig_y) + MDX_C2;
-    const float d = B1 * B2;
-    const float q = quot_rcp(n, d).q;
-    return clamp01((1.0f - q) / 2.0f);
-}
-
 // GRAD = true: the training form (loss, indices AND the unit-upstream gradients).  GRAD = false: validation /
 // torch.no_grad() (model_train.py:75-79 runs the loss on the validation split every epoch): the same marching wave
 // without the coefficient histories, the stash and the gradient phase -- every scale's forward in ONE launch.
@@ -358,7 +100,7 @@ MDX_DEV float ssim_val(const SsimTerms &s, const TStat &t)
 constexpr bool train_low(int S, bool grad) { return grad && S >= 3; }
 constexpr int train_waves(int S, bool grad)
 {
-    return grad ? (S <= 2 ? 3 : (S == 3 ? 3 : 2)) : (S <= 3 ? 4 : 3);
+    return grad ? (S == 1 ? 4 : (S <= 3 ? 3 : 2)) : (S <= 3 ? 4 : 3);
 }
 template <int S, bool GRAD, bool PRE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(train_waves(S, GRAD), GRAD ? train_waves(S, GRAD) : 8))) void photometric_train_kernel(TrainArgs a)
@@ -545,6 +287,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(train_waves(
 
     // ---- prefetch registers: the loads of the NEXT step whose addresses do not depend on computed data ----
     float pf_y[3], pf_d[4], pf_id[S], pf_nz[S];
+    float pf_tyl1 = 0.f;                   // the prefetched row's bilinear y weight (wave-uniform; one register instead of
+                                           // ten dependent instructions to form it again at the head of the next step)
     f32x4 pf_ts4 = {0.f, 0.f, 0.f, 0.f};   // PRE: mu_y[0..2], sigma_y[0]
     float2_a4 pf_ts2 = {0.f, 0.f};         //      sigma_y[1..2]
     u32x2_a4 pf_bf = {0u, 0u};             //      best identity value (float bits), its index
@@ -567,6 +311,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(train_waves(
             // the four disparity taps at 32-bit element offsets from the (scalar) map base: row pointers formed from the
             // per-lane row index were 64-bit VALU address arithmetic
             const UpTap ty = up_tap((float)d.h / (float)H, pyr, d.h);
+            pf_tyl1 = ty.l1;
             const unsigned o0 = (unsigned)(ty.i0 * d.w), o1 = (unsigned)(ty.i1 * d.w);
             const UpTap tx = tx_tap();
             pf_d[0] = at32(disp_b, o0 + (unsigned)tx.i0); pf_d[1] = at32(disp_b, o0 + (unsigned)tx.i1);
@@ -629,7 +374,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(train_waves(
             if (same_res) {
                 up = pf_d[0];
             } else {
-                const UpTap ty = up_tap((float)d.h / (float)H, pyr, d.h);
+                UpTap ty;                  // (i0, i1 served the prefetch's addresses; the weights are all that is left to use)
+                ty.i0 = ty.i1 = 0;
+                ty.l1 = pf_tyl1;
+                ty.l0 = 1.0f - pf_tyl1;
                 up = up_combine(pf_d[0], pf_d[1], pf_d[2], pf_d[3], ty, tx_tap(), premul);
             }
             float iK[12], Pm[S][12];
@@ -950,14 +698,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(train_waves(
                     dv[c] = (gc[c].sw - gc[c].nw) * dx1 + (gc[c].se - gc[c].ne) * dx0;
                 }
             }
+            // the three colour channels in lock step (three independent chains instead of one after the other)
+            float gxc[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) gxc[c] = 2.0f * xh[0][f][c];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) gxc[c] = __builtin_fmaf(gxc[c], sum3[c][1], sum3[c][0]);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) gxc[c] = __builtin_fmaf(yh[0][c], sum3[c][2], gxc[c]);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const float xq = xh[0][f][c], yq = yh[0][c];
-                float gx = (sum3[c][0] + 2.0f * xq * sum3[c][1] + yq * sum3[c][2]) * (1.0f / 9.0f);
-                if (centre) gx -= 0.05f * ((yq > xq) ? 1.f : ((yq < xq) ? -1.f : 0.f));   // 0.15*mean_c|y-x|
-                gu += gx * du[c];
-                gv += gx * dv[c];
+                const float l1 = centre ? 0.05f * ((yq > xq) ? 1.f : ((yq < xq) ? -1.f : 0.f)) : 0.f;   // 0.15*mean_c|y-x|
+                gxc[c] = __builtin_fmaf(gxc[c], 1.0f / 9.0f, -l1);
             }
+            gu = __builtin_fmaf(gxc[2], du[2], __builtin_fmaf(gxc[1], du[1], gxc[0] * du[0]));
+            gv = __builtin_fmaf(gxc[2], dv[2], __builtin_fmaf(gxc[1], dv[1], gxc[0] * dv[0]));
             // grid normalisation (2/(W-1)) and grid_sample's un-normalisation ((W-1)/2) cancel
             gu = ((LOW ? gt.inx : (((flp >> (2 * f)) & 1) != 0)) && out_lane) ? gu : 0.f;
             gv = ((LOW ? gt.iny : (((flp >> (2 * f + 1)) & 1) != 0)) && out_lane) ? gv : 0.f;
@@ -1081,7 +837,9 @@ static void choose_levels(const mdx_train_desc *d, TrainPlan &p, bool grad)
         if (H >= 256 && grad) {
             // BASELINE configs[3] (320 x 1024), swept in round 4 (tools/r4_sweep.sh, inside the real step): 4 x 48 + 3 x 24 + 5 x 12
             // rows 378.5 us against 390.9 us for 40 / 20 / 10 at 0.6 / 0.25 (16 chunks); 64 / 32 / 16: 387.5; 56 / 28 / 14: 397.8
-            r[0] = 48; r[1] = 24; r[2] = 12; f1 = 0.6; f2 = 0.225;
+            // (48 / 28 / 9 at 0.6 / 0.27 -- the taller-middle, shorter-tail pattern that won at H = 192 -- is another 1 %:
+            // 387.8 / 390.5 us against 391.2 / 394.3 us in one run)
+            r[0] = 48; r[1] = 28; r[2] = 9; f1 = 0.6; f2 = 0.27;
         }
         if (H >= 160 && H < 256) {
             // re-swept in round 3 for the BASELINE height (tools/sweep_schedule.sh, timing inside the real step): with the
@@ -1089,6 +847,10 @@ static void choose_levels(const mdx_train_desc *d, TrainPlan &p, bool grad)
             // 3 x 40 + 2 x 24 + 2 x 12 rows (7 chunks, 220 steps per column) 210.5 us against 223.7 us for round 2's
             // 2 x 40 + 2 x 20 + 8 x 10 (12 chunks, 240 steps); 3 x 40 + 3 x 24 (6 chunks) is unbalanced again (224.6 us)
             r[1] = 24; r[2] = 12; f1 = 0.63; f2 = 0.25;
+            // round 4, after the row loop got cheaper where a frame wins (contraction, lock-step): a taller middle level and a
+            // shorter last one -- 3 x 40 + 2 x 26 + 2 x 10 rows 192.3 us (mean of five runs) against 195.8 us for 24 / 12 in the
+            // same runs; configs[4] (S = 3) 276.6 against 279.8 us (tools/r4_sweep.sh, profiles/r04_schedule_sweep.txt)
+            if (grad) { r[1] = 26; r[2] = 10; f2 = 0.28; }
             // the forward-only form (validation, torch.no_grad()): two halo rows per chunk instead of four, 4 waves per SIMD
             // instead of 3, no gradient phase whose cost varies with the mask -- many short chunks balance better than few
             // tall ones (tools/sweep_schedule_eval.sh on bench.py's batch: 16/8/4 rows 116.5 us, 20/10/5 117.5, 24/12/6

@@ -46,9 +46,10 @@ def test_self_launch_two_ranks_gloo():
 
 
 def test_committed_counter_summary_matches_the_sources():
-    """bench.py quotes profiles/r03_bench_kernel_pmc.json (traffic, VALU issue) only for the build it was taken on, recognised by
-    the hash of the kernel sources and flags.  A source change without a new counter pass makes those fields null in the bench
-    line: this test says so (skip, not failure: the numbers' absence is reported by bench.py itself)."""
+    """bench.py quotes profiles/r04_bench_kernel_pmc.json, r04_pmc_c4.json, r04_pmc_c3.json (traffic, vector-ALU busy time) only
+    for the build they were taken on, recognised by the hash of the kernel sources and flags, and for their workload shape.  The
+    three files must come from ONE build; a source change without a new counter pass makes those fields null in the bench line:
+    this test says so (skip, not failure: the numbers' absence is reported by bench.py itself)."""
     import importlib.util
     import json
     import pytest
@@ -57,8 +58,14 @@ def test_committed_counter_summary_matches_the_sources():
     spec = importlib.util.spec_from_file_location("_mdx_build_t", os.path.join(pkg, "build.py"))
     b = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(b)
-    pmc = json.load(open(os.path.join(root, "profiles", "r03_bench_kernel_pmc.json")))
     assert len(b.source_sha16()) == 16
-    if pmc.get("source_sha16") != b.source_sha16():
-        pytest.skip("profiles/r03_bench_kernel_pmc.json was taken on other kernel sources (%s, now %s): run "
-                    "tools/profile_round3.sh on the GPU box and --collect" % (pmc.get("source_sha16"), b.source_sha16()))
+    shapes = {"r04_bench_kernel_pmc.json": [12, 192, 640, 2, 4], "r04_pmc_c4.json": [12, 192, 640, 3, 4], "r04_pmc_c3.json": [8, 320, 1024, 2, 4]}
+    pmcs = {n: json.load(open(os.path.join(root, "profiles", n))) for n in shapes}
+    assert all(pmcs[n]["shape"] == shapes[n] for n in shapes)
+    assert len({p["source_sha16"] for p in pmcs.values()}) == 1, "the three counter files come from different builds"
+    for n, p in pmcs.items():
+        assert any("photometric_train_kernel" in k and "valu_busy_us" in v for k, v in p["kernels"].items()), n
+    have = next(iter(pmcs.values()))["source_sha16"]
+    if have != b.source_sha16():
+        pytest.skip("profiles/r04_*pmc*.json were taken on other kernel sources (%s, now %s): run tools/r4_pmc_configs.sh on the "
+                    "GPU box and tools/pmc_to_json.py" % (have, b.source_sha16()))

@@ -302,3 +302,36 @@ def test_ssim_module_backward_vs_autograd(G, saturate):
         g, r = g.cpu().numpy().astype(np.float64), r.numpy()
         err = np.abs(g - r)[ok].max() / (np.abs(r).max() + 1e-30)
         assert err <= 1e-4, "d ssim / d %s: rel err %g" % (name, err)
+
+
+@pytest.mark.parametrize("shape", [(2, 24, 40), (3, 17, 23), (1, 96, 320)])
+def test_smoothness_two_launch_form_vs_float64_composite(G, shape):
+    """csrc/smooth.hip (round 4: main pass on the disparity as given + finishing pass) against the reference formula
+    (model_loss.py:77-88, 112-115) evaluated in float64: SmoothLoss, the bare EdgeAwareSmooth (normalize = 0: m = 1 exactly),
+    a width that is not a multiple of 4 (the one-pixel-per-thread form), and a disparity with a NEGATIVE mean -- the identities
+    |d_i/m - d_j/m| = |d_i - d_j| / |m| and sign(d_i/m - d_j/m) = sign(m) sign(d_i - d_j) hold for any m != 0."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import torch_composite as tc
+    B, h, w = shape
+    rng = np.random.RandomState(h * w)
+    color = rng.rand(B, 3, h, w).astype(np.float32)
+    for sign in (1.0, -1.0):
+        disp = (sign * (0.05 + rng.rand(B, 1, h, w))).astype(np.float32)
+        up = float(rng.rand() + 0.5)
+        for normalize in (True, False):
+            d = G.t(disp).requires_grad_(True)
+            out = G.F.smooth_loss(d, G.t(color), normalize=normalize)
+            (out * up).backward()
+            dr = torch.from_numpy(disp).double().requires_grad_(True)
+            cr = torch.from_numpy(color).double()
+            if normalize:
+                ref = tc.smooth_loss(dr, cr)
+            else:
+                gx = torch.abs(dr[:, :, :, :-1] - dr[:, :, :, 1:]) * torch.exp(-torch.abs(cr[:, :, :, :-1] - cr[:, :, :, 1:]).mean(1, True))
+                gy = torch.abs(dr[:, :, :-1, :] - dr[:, :, 1:, :]) * torch.exp(-torch.abs(cr[:, :, :-1, :] - cr[:, :, 1:, :]).mean(1, True))
+                ref = gx.mean() + gy.mean()
+            (ref * up).backward()
+            G.assert_close(out, ref.detach().numpy(), "smooth loss (sign %+d, normalize %d)" % (sign, normalize))
+            G.assert_close(d.grad, dr.grad.numpy(), "smooth gradient (sign %+d, normalize %d)" % (sign, normalize))

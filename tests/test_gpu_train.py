@@ -128,6 +128,7 @@ def _oracle_case(G, B, H, W, S, seed, nscales=4, automask=True, grads=True, rows
     (1, 192, 640, 2, 2, False),     # use_automasking = False
     (3, 64, 68, 1, 4, True),        # single source frame, W just over one strip
     (1, 192, 640, 4, 1, True),      # MDX_MAX_SRC
+    (2, 64, 160, 3, 2, False),      # S = 3 (the LOW form: accumulators / coefficient rows in LDS, (u, v) ring) without auto-masking
 ])
 def test_train_kernel_vs_oracle_full_size(G, B, H, W, S, nscales, automask):
     _oracle_case(G, B, H, W, S, seed=4321 + S, nscales=nscales, automask=automask)
