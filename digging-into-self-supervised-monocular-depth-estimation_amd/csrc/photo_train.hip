@@ -401,7 +401,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(train_waves(
             for (int f = 0; f < S; ++f) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
-                    cn[f][c] = load_corners(a.src.img[f] + ((size_t)b * 3 + c) * HW, H, W, tp[f]);
+                    cn[f][c] = load_corners_finite(a.src.img[f] + ((size_t)b * 3 + c) * HW, H, W, tp[f]);
             }
             prefetch_warp_row(wr + 1);
             // PRE: this step's SSIM row -- three loads whose latency the sampling arithmetic below covers; fetched a step
@@ -552,11 +552,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(train_waves(
             }
             if constexpr (GRAD) {
                 if (!ssim_lane) fr = -1;
-                const bool keep = fr >= 0;
+                // the candidate as it stands: where no reprojection frame is this lane's arg-min (fr = -1) the row's
+                // selection code below is 0 and the gradient phase weights the row with 0 for every frame -- the (finite)
+                // values need no clearing (nine selects per step)
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) ch[CN][c][k] = keep ? cand[c][k] : 0.f;
+                    for (int k = 0; k < 3; ++k) ch[CN][c][k] = cand[c][k];
                 selp |= (fr + 1) << 8;
             }
             // `best` and `bi` are pinned in front of the store branch by an empty volatile asm.  In the forward-only form
@@ -637,7 +639,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(train_waves(
                 sa.w = uv.x; sb.w = uv.y;
                 gt = make_tap((div_norm(uv.x, nd.w) - 0.5f) * 2.0f, (div_norm(uv.y, nd.h) - 0.5f) * 2.0f, H, W);
 #pragma unroll
-                for (int c = 0; c < 3; ++c) gc[c] = load_corners(a.src.img[f] + ((size_t)b * 3 + c) * HW, H, W, gt);
+                for (int c = 0; c < 3; ++c) gc[c] = load_corners_finite(a.src.img[f] + ((size_t)b * 3 + c) * HW, H, W, gt);
             } else {
                 sa = s_stash[slot_r][2 * f][lane];
                 sb = s_stash[slot_r][2 * f + 1][lane];

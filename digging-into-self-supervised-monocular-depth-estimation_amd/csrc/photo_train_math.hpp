@@ -197,6 +197,32 @@ MDX_DEV Proj project_point_train(const float *__restrict__ P, float X0, float X1
     return p;
 }
 
+// load_corners() (mdx_device.hpp) for FINITE images, with two selects per colour channel instead of six.  A corner that lies
+// outside the image reads as 0 in the reference (ATen's masked gather).  It lies outside only when the clipped coordinate
+// sits exactly on the last column / row: x0 = floor(ix) = W-1 forces ix = W-1, hence the east weights s*w, n*w are s*(+0),
+// n*(+0) = +0 -- and likewise the south weights when y0 = H-1.  A finite value times a zero weight adds a signed zero to
+// the fma chain of sample(), which leaves every accumulator value as it is (x + (+-0) = x; the one sign-of-zero case, -0 + +0,
+// comes out +0 here and in the reference alike), so the out-of-range corner may hold ANY finite number: the neighbouring
+// in-range pixel the 8-byte load brings along anyway.  The sampling derivatives use such a corner only in terms that are
+// multiplied by dx0 = ix - x0 = 0 (dy0 = 0) or masked out by the coordinate's "strictly inside" flag.  Only NaN / Inf pixels
+// would tell the difference; the colours here are bytes / 255.
+MDX_DEV Corners load_corners_finite(const float *__restrict__ img, int H, int W, const Tap &t)
+{
+    const int xl = t.x0 < W - 1 ? t.x0 : W - 2;
+    const bool shifted = xl != t.x0;            // x0 == W-1: the pair is anchored one column to the left
+    const int y1 = t.y0 + 1 < H ? t.y0 + 1 : t.y0;
+    const unsigned o0 = (unsigned)(t.y0 * W + xl) * 4u, o1 = (unsigned)(y1 * W + xl) * 4u;
+    const char *base = reinterpret_cast<const char *>(img);
+    const float2_a4 top = *reinterpret_cast<const float2_a4 *>(base + o0);
+    const float2_a4 bot = *reinterpret_cast<const float2_a4 *>(base + o1);
+    Corners c;
+    c.nw = shifted ? top.y : top.x;
+    c.ne = top.y;
+    c.sw = shifted ? bot.y : bot.x;
+    c.se = bot.y;
+    return c;
+}
+
 // geom_from_disp() (photo_common.hpp) with the written-out reciprocal
 MDX_DEV PixelGeom geom_from_disp_train(const mdx_desc &d, float up, const float *__restrict__ invK_b, int px, int py)
 {

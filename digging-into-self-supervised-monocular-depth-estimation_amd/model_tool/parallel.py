@@ -78,7 +78,7 @@ def grad_view(flat, offset, p):
             raise ValueError("grad_sync: parameter of shape %s has strides %s (not dense)" % (tuple(p.shape), p.stride()))
         expect *= sz
     # the parameter's strides verbatim, size-1 dimensions included: the fused optimiser compares stride tuples
-    return flat.as_strided(p.shape, p.stride(), storage_offset=offset)
+    return flat.as_strided(p.shape, p.stride(), storage_offset=flat.storage_offset() + offset)
 
 
 def _align(n, a=64):

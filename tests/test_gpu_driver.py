@@ -177,12 +177,13 @@ def test_kitti_tree_training_and_eigen_style_evaluation(G, tmp_path):
     assert 0 <= res["a1"] <= res["a2"] <= res["a3"] <= 1
 
 
-def _trainer_losses(graph, automask=False, noise="device", n=6, lr_change_at=4, amp="none", channels_last=False, batches=None):
+def _trainer_losses(graph, automask=False, noise="device", n=6, lr_change_at=4, amp="none", channels_last=False, batches=None,
+                    frame_ids=(0, -1, 1)):
     import importlib
     bench = importlib.import_module("bench")
     from model_train import trainer
     torch.manual_seed(0)
-    opt = bench.make_opt(2, height=64, width=96, amp=amp)
+    opt = bench.make_opt(2, height=64, width=96, amp=amp, frame_ids=frame_ids)
     opt.use_automasking, opt.graph, opt.synthetic_length, opt.max_steps, opt.miopen_find = automask, graph, 16, 0, False
     opt.noise, opt.channels_last = noise, channels_last
     tr = trainer(opt)
@@ -230,6 +231,19 @@ def test_trainer_graph_replay_matches_eager(G):
     torch.cuda.current_stream().wait_stream(tr._graphed.stream)
     o2 = float(tr._graphed(dict(tr._graphed.static))["loss"].detach())
     assert np.isfinite(o1) and np.isfinite(o2) and abs(o1 - o2) < 0.05 * abs(o1)
+
+
+def test_trainer_mono_stereo_captured_step_matches_eager(G):
+    """BASELINE configs[4] (frame_ids 0, -1, 1, "s": three source frames -- the training kernel's LOW form with its (u, v) ring in
+    the workspace and its accumulators in LDS) through the trainer: six steps captured into a hipGraph and replayed follow the
+    eager steps, with auto-masking on (the in-kernel noise offset is restored around the warm-up: same draws)."""
+    fids = (0, -1, 1, "s")
+    eager, n_e, tr_e = _trainer_losses(False, automask=True, frame_ids=fids)
+    graph, n_g, tr_g = _trainer_losses(True, automask=True, frame_ids=fids)
+    assert tr_g._graphed is not None and tr_e._graphed is None and n_e == n_g == 6
+    assert len(tr_g.opt.frame_ids) == 4 and tr_g.compute.noise_offset() == 6
+    _same_trajectory(graph, eager)
+    assert eager[-1] < eager[0]
 
 
 def test_trainer_host_noise_is_never_captured(G):

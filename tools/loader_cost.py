@@ -148,13 +148,11 @@ def rank_child(root, k, workers, batch, seconds, pin, height, width, frames=(0, 
     """One rank's DataLoader set of the host-feed rehearsal (--ranks): gpu_prep path (the workers only decode), uint8 frames,
     collate_raw_step_keys, optionally pinned -- what model_train.trainer builds; no GPU work.  Warm-up, then wait for the
     parent's go file so that every set measures while all the others run."""
-    import fake_kitti
     from torch.utils.data import DataLoader, Dataset
     from model_loader import KITTIMonoDataset_v2
     from model_tool.loader import collate_raw_step_keys
     torch.set_num_threads(1)
-    names = fake_kitti.names(root) if hasattr(fake_kitti, "names") else sorted(
-        ln.strip() for ln in open(os.path.join(root, "names.txt")))
+    names = [ln.strip() for ln in open(os.path.join(root, "names.txt")) if ln.strip()]      # written by rehearse()
     ds = KITTIMonoDataset_v2(root, names, True, list(frames), height, width, "jpg", 4)
     ds.uint8, ds.gpu_prep = True, True
 
