@@ -27,6 +27,8 @@ def test_oracle_full_size_vs_reference(name):
     c = goldens_r2.FullCase(name)
     if name.startswith("r3"):      # most pixels carry a photometric gradient (round 2's fixture: fewer than a fifth)
         assert (c["idx_s1"] >= 2).mean() > 0.6
+    if name.startswith("r4"):      # three source frames, each of them the arg-min somewhere
+        assert c.S == 3 and all((c["idx_s0"] == 3 + j).mean() > 0.1 for j in range(3))
     P = np.stack([orc.compose_projection(c["K"], c["T_%s" % f]) for f in c.sources_ids])
     srcs = [c.color(f) for f in c.sources_ids]
     n = c.B * c.H * c.W
@@ -46,7 +48,8 @@ def test_oracle_full_size_vs_reference(name):
         gP_tot = gP_tot + gP.astype(np.float64)
     assert_close(total / len(c.scales), c["loss"], "loss", rel=1e-5)
     for i, f in enumerate(c.sources_ids):
-        assert_close(orc.compose_projection_bwd(c["K"], gP_tot[i].astype(np.float32)), c["grad_T_%s" % f], "grad T %s" % f)
+        if f != "s":                   # inputs["stereo"] is a constant of the data layer
+            assert_close(orc.compose_projection_bwd(c["K"], gP_tot[i].astype(np.float32)), c["grad_T_%s" % f], "grad T %s" % f)
 
 
 def _run_decoder(dec, z, device):
