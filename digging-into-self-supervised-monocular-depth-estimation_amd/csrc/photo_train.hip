@@ -509,16 +509,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(train_waves(
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     pool3_n<3>(q, o);
-                    if constexpr (GRAD) {
-                        po[c][0] = o[0]; po[c][1] = o[1]; po[c][2] = o[2];
-                    } else {
-                        SsimTerms st;
-                        st.mu_x = o[0]; st.ex2 = o[1]; st.exy = o[2];
-                        ss[c] = ssim_val(st, ts[c]);
-                    }
+                    po[c][0] = o[0]; po[c][1] = o[1]; po[c][2] = o[2];
                     ad[c] = fabsf(yh[1][c] - xh[1][f][c]);
                 }
-                if constexpr (GRAD) ssim_value_mid3(po, ts, mid, ss);
+                ssim_value_mid3(po, ts, mid, ss);      // (forward-only form: the intermediates kept in `mid` are dead code)
                 const float rl = reprojection_combine(ss, ad);
                 const bool better = f == 0 || rl < best_r;
                 best_r = better ? rl : best_r;

@@ -270,25 +270,4 @@ static __device__ __forceinline__ void swait12(SRows &m, float *o)     // the lo
     o[8] = m.c.x; o[9] = m.c.y; o[10] = m.c.z; o[11] = m.c.w;
 }
 
-// SSIM value alone (the no-gradient form of the kernel): ssim_raw()'s operation order, bit-equal to ssim_both().val
-MDX_DEV float ssim_val(const SsimTerms &s, const TStat &t)
-{
-    const float mxx = s.mu_x * s.mu_x;
-    const float mxy = s.mu_x * t.mu;
-    const float sig_x = s.ex2 - mxx;
-    const float sig_y = t.sig_y;
-    const float sig_xy = s.exy - mxy;
-    float a = 2.0f * s.mu_x;
-    a = a * t.mu;
-    const float A1 = a + MDX_C1;
-    float A2 = 2.0f * sig_xy;
-    A2 = A2 + MDX_C2;
-    const float n = A1 * A2;
-    const float B1 = (mxx + t.mu2) + MDX_C1;
-    const float B2 = (sig_x + sig_y) + MDX_C2;
-    const float d = B1 * B2;
-    const float q = quot_rcp(n, d).q;
-    return clamp01((1.0f - q) / 2.0f);
-}
-
 }  // namespace mdx
