@@ -92,6 +92,37 @@ def test_round3_entry_points_report_bad_arguments():
     assert lib.mdx_to_tensor_u8(fake, C.c_void_p(4100), C.c_size_t(16), None) == -6      # destination not 16-byte aligned
 
 
+def test_round4_workspace_contracts():
+    """Host-side size functions of the entries whose insides changed in round 4 (no GPU needed).  mdx_photometric_train: at
+    S >= 3 the workspace also holds the items' (u, v) rings -- 3 rows x S planes x 64 lanes x 8 bytes per work item -- and a
+    caller that hands over less is told so (MDX_ERR_WORKSPACE) before anything is launched.  mdx_smooth_loss(_multi): four
+    doubles per block of the main pass and image."""
+    lib = _lib.lib()
+    hw = [(192, 640), (96, 320), (48, 160), (24, 80)]
+    w2 = lib.mdx_photometric_train_workspace_bytes(C.byref(_lib.make_train_desc(12, 192, 640, 2, hw, True, 0.1, 100.0)))
+    w3 = lib.mdx_photometric_train_workspace_bytes(C.byref(_lib.make_train_desc(12, 192, 640, 3, hw, True, 0.1, 100.0)))
+    items = 4 * 12 * 11 * 7          # scales x images x strips of 60 columns x chunks of a 192-row column
+    gup = 4 * 12 * 192 * 640 * 4     # the full-resolution gradient maps of the scales
+    ring = items * 3 * 3 * 512
+    assert gup + ring <= w3 < gup + ring + (1 << 20), (w3, gup, ring)
+    assert gup <= w2 < gup + (2 << 20), (w2, gup)          # S = 2: the register form, no ring
+    td = _lib.make_train_desc(1, 32, 64, 3, [(32, 64)], True, 0.1, 100.0)
+    fake = C.c_void_p(4096)
+    arr = (C.c_void_p * 1)(4096)
+    src = _lib.Sources()
+    for f in range(3):
+        src.img[f] = 4096
+    need = lib.mdx_photometric_train_workspace_bytes(C.byref(td))
+    rc = lib.mdx_photometric_train_pre(C.byref(td), arr, fake, C.byref(src), fake, arr, fake, arr, None, arr, fake, arr, fake,
+                                       None, None, fake, C.c_size_t(need - 1), None, None)
+    assert rc == -3, rc                                   # MDX_ERR_WORKSPACE
+    one = lib.mdx_smooth_workspace_bytes(12, 192, 640)
+    assert one == 12 * ((192 * 640 + 255) // 256) * 4 * 8
+    hs, ws = (C.c_int32 * 4)(192, 96, 48, 24), (C.c_int32 * 4)(640, 320, 160, 80)
+    assert lib.mdx_smooth_multi_workspace_bytes(4, 12, hs, ws) >= one
+    assert lib.mdx_smooth_loss_multi(4, 12, hs, ws, arr, arr, 1, fake, None, fake, C.c_size_t(one), None) in (-2, -3)
+
+
 def test_cpu_tensors_are_refused_loudly():
     import torch
     from mdx import functional as F
