@@ -84,12 +84,31 @@ def collate_raw(samples, keep=None):
     if raw_keys:
         hmax = max(int(s[raw_keys[0]].shape[0]) for s in samples)
         wmax = max(int(s[raw_keys[0]].shape[1]) for s in samples)
+        ragged_frames = any(tuple(s[raw_keys[0]].shape[:2]) != (hmax, wmax) for s in samples)
         for k in raw_keys:
-            block = torch.zeros(len(samples), hmax, wmax, 3, dtype=torch.uint8)
+            # 16.8 MB per frame id at batch 12: allocated IN shared memory when this runs in a DataLoader worker (what
+            # default_collate does for its stacks) -- a block built in private memory is copied into shared memory when the
+            # batch is put on the queue -- and cleared only when frames of different sizes leave padding
+            block = _batch_block((len(samples), hmax, wmax, 3), torch.uint8)
+            if ragged_frames:
+                block.zero_()
             for n, s in enumerate(samples):
                 block[n, : s[k].shape[0], : s[k].shape[1]] = s[k]
             rest[k] = block
     return rest
+
+
+def _batch_block(shape, dtype):
+    """An uninitialised tensor for a collated batch entry; in a DataLoader worker its storage lives in shared memory."""
+    from torch.utils.data import get_worker_info
+    if get_worker_info() is None:
+        return torch.empty(shape, dtype=dtype)
+    numel = 1
+    for v in shape:
+        numel *= int(v)
+    elem = torch.empty(0, dtype=dtype)
+    storage = elem._typed_storage()._new_shared(numel, device=elem.device)
+    return elem.new(storage).resize_(*shape)
 
 
 class KITTIDataset(Dataset):
