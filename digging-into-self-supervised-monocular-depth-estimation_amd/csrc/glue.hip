@@ -73,47 +73,67 @@ __global__ __launch_bounds__(GX *GY) void decoder_glue_fwd_kernel(const TI *__re
     }
 }
 
-// sum of the padded-gradient positions that reflect onto unpadded (y, x); gp = plane [Hp][Wp]
-template <typename T> __device__ __forceinline__ float fold_pad(const T *__restrict__ gp, int y, int x, int H, int W)
+// Sum of the padded-gradient positions that reflect onto unpadded (y, x); gp = plane [Hp][Wp].  The position's own image
+// (y+1, x+1) always exists and comes first in the sum; the up to eight others exist only on the rows 1 / H-2 and columns
+// 1 / W-2.  Round 4: the own position is loaded UNCONDITIONALLY by the callers (all rows and sub-pixels of a thread back to back)
+// and the others are added under one rare branch -- with every one of the nine positions behind its own `if`, each load sat in
+// an exec-masked block followed by s_waitcnt vmcnt(0): 36 memory round trips in a row per thread of the raw-gradient kernel
+// (tools/isa_loadwaits.py).  Same terms in the same order: the same bits.
+__device__ __forceinline__ bool on_fold_ring(int y, int x, int H, int W) { return y == 1 || y == H - 2 || x == 1 || x == W - 2; }
+template <typename T> __device__ __forceinline__ float fold_rest(float acc, const T *__restrict__ gp, int y, int x, int H, int W)
 {
     const int Wp = W + 2;
     const int ys[3] = {y + 1, y == 1 ? 0 : -1, y == H - 2 ? H + 1 : -1};
     const int xs[3] = {x + 1, x == 1 ? 0 : -1, x == W - 2 ? W + 1 : -1};
-    float acc = 0.f;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         if (ys[i] < 0) continue;
 #pragma unroll
         for (int j = 0; j < 3; ++j)
-            if (xs[j] >= 0) acc += to_float(gp[(size_t)ys[i] * Wp + xs[j]]);
+            if (xs[j] >= 0 && (i | j) != 0) acc += to_float(gp[(size_t)ys[i] * Wp + xs[j]]);
     }
     return acc;
 }
 
 // ---- decoder glue, backward w.r.t. raw.  grid: (ceil(w/64), ceil(h/4), B*C1) ----
-template <typename TI, typename TO>
+template <typename TI, typename TO, int U>
 __global__ __launch_bounds__(GX *GY) void decoder_glue_bwd_raw_kernel(const TO *__restrict__ gout, const TI *__restrict__ raw,
                                                                        const float *__restrict__ bias, TI *__restrict__ graw,
                                                                        float *__restrict__ bias_part, int C1, int C2, int h,
-                                                                       int w, int up, int elu)
+                                                                       int w, int elu)
 {
     __shared__ float lds[GX * GY / 64];
-    const int u = up ? 2 : 1;
-    const int H = h * u, W = w * u;
+    const int H = h * U, W = w * U, Wp = W + 2;
     const int xx_raw = blockIdx.x * GX + threadIdx.x, y0 = blockIdx.y * (GY * RPT) + threadIdx.y;
     const bool in_x = xx_raw < w;
     const int xx = in_x ? xx_raw : 0;
     const int bc = blockIdx.z, b = bc / C1, c = bc - b * C1;
-    const TO *gp = gout + ((size_t)b * (C1 + C2) + c) * (size_t)(H + 2) * (W + 2);
+    const TO *gp = gout + ((size_t)b * (C1 + C2) + c) * (size_t)(H + 2) * Wp;
     const float bv = bias ? bias[c] : 0.f;
-    float g[RPT], rv[RPT];
+    float own[RPT][U * U], rv[RPT];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        const int yy = (y0 + r * GY < h) ? y0 + r * GY : 0;
+#pragma unroll
+        for (int dy = 0; dy < U; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < U; ++dx) own[r][dy * U + dx] = to_float(gp[(size_t)(U * yy + dy + 1) * Wp + (U * xx + dx + 1)]);
+        rv[r] = to_float(raw[((size_t)bc * h + yy) * w + xx]);
+    }
+    float g[RPT];
 #pragma unroll
     for (int r = 0; r < RPT; ++r) {
         const int yy = (y0 + r * GY < h) ? y0 + r * GY : 0;
         g[r] = 0.f;
-        for (int dy = 0; dy < u; ++dy)
-            for (int dx = 0; dx < u; ++dx) g[r] += fold_pad(gp, u * yy + dy, u * xx + dx, H, W);
-        rv[r] = elu ? to_float(raw[((size_t)bc * h + yy) * w + xx]) + bv : 1.f;
+#pragma unroll
+        for (int dy = 0; dy < U; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < U; ++dx) {
+                float f = own[r][dy * U + dx];
+                if (on_fold_ring(U * yy + dy, U * xx + dx, H, W)) f = fold_rest(f, gp, U * yy + dy, U * xx + dx, H, W);
+                g[r] += f;
+            }
+        rv[r] = elu ? rv[r] + bv : 1.f;
     }
     float bsum = 0.f;
 #pragma unroll
@@ -163,11 +183,12 @@ __global__ __launch_bounds__(GX *GY) void decoder_glue_bwd_skip_kernel(const TO 
     const TO *gp = gout + ((size_t)b * (C1 + C2) + C1 + c) * (size_t)(H + 2) * (W + 2);
     float g[RPT];
 #pragma unroll
-    for (int r = 0; r < RPT; ++r) g[r] = fold_pad(gp, (y0 + r * GY < H) ? y0 + r * GY : 0, x, H, W);
+    for (int r = 0; r < RPT; ++r) g[r] = to_float(gp[(size_t)(((y0 + r * GY < H) ? y0 + r * GY : 0) + 1) * (W + 2) + x + 1]);
 #pragma unroll
     for (int r = 0; r < RPT; ++r) {
         const int y = y0 + r * GY;
         if (y >= H) break;
+        if (on_fold_ring(y, x, H, W)) g[r] = fold_rest(g[r], gp, y, x, H, W);
         gskip[((size_t)bc * H + y) * W + x] = from_float<TI>(g[r]);
     }
 }
@@ -335,8 +356,12 @@ MDX_EXPORT int mdx_decoder_glue_bwd(const void *gout, const void *raw, const flo
     hipStream_t st = (hipStream_t)stream;
 #define MDX_GLUE_BWD(TI, TO)                                                                                          \
     do {                                                                                                              \
-        hipLaunchKernelGGL((decoder_glue_bwd_raw_kernel<TI, TO>), graw_grid, block, 0, st, (const TO *)gout,          \
-                           (const TI *)raw, bias, (TI *)graw, bias_part, C1, C2, h, w, upsample, elu);                 \
+        if (upsample)                                                                                                 \
+            hipLaunchKernelGGL((decoder_glue_bwd_raw_kernel<TI, TO, 2>), graw_grid, block, 0, st, (const TO *)gout,   \
+                               (const TI *)raw, bias, (TI *)graw, bias_part, C1, C2, h, w, elu);                       \
+        else                                                                                                          \
+            hipLaunchKernelGGL((decoder_glue_bwd_raw_kernel<TI, TO, 1>), graw_grid, block, 0, st, (const TO *)gout,   \
+                               (const TI *)raw, bias, (TI *)graw, bias_part, C1, C2, h, w, elu);                       \
         if (C2 > 0)                                                                                                   \
             hipLaunchKernelGGL((decoder_glue_bwd_skip_kernel<TI, TO>), gskip_grid, block, 0, st, (const TO *)gout,    \
                                (TI *)gskip, C1, C2, h * u, w * u);                                                     \

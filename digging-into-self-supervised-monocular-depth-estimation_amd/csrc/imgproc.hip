@@ -233,45 +233,75 @@ static __device__ __forceinline__ void resample_h_rows(const PackedJob &J, const
     const int a0 = (3 * px_lo) & ~15;
     const int nch = min((3 * px_hi + 3 - a0 + 15) >> 4, (pitch - 12) >> 4);
     const unsigned total = (unsigned)in_h * (unsigned)J.in_stride;            // bytes of the image's rows (its slot may be larger)
-    // 16 lanes per row, 16 rows per sweep (no division by run-time values anywhere in this kernel: an emulated integer
-    // division is ~40 vector instructions -- the first version spent more of them on its index arithmetic than on the taps)
-    for (int r = tid >> 4; r < HW_ROWS; r += 16) {
-        const int y = min(yb + r, in_h - 1);
-        const unsigned row_off = (unsigned)y * (unsigned)J.in_stride + (unsigned)a0;
-        for (int ch = tid & 15; ch < nch; ch += 16) {
-            const unsigned off = row_off + 16u * (unsigned)ch;
-            u32x4_t v;
-            if (off + 16u <= total) {
-                __builtin_memcpy(&v, J.src + off, 16);                         // one unaligned global_load_dwordx4
-            } else {                                                           // the image's last bytes: nothing past them is read
-                uint8_t b[16];
-#pragma unroll
-                for (int e = 0; e < 16; ++e) b[e] = off + e < total ? J.src[off + e] : 0;
-                __builtin_memcpy(&v, b, 16);
-            }
-            unsigned *d = reinterpret_cast<unsigned *>(lds + r * pitch + 16 * ch);  // 4-byte aligned only: the pitch is 4 x odd
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-        }
-    }
-    // the weights of the block's columns, transposed to [column][tap] (rows of an odd number of dwords): a wave then
-    // fetches one column's taps with ONE conflict-free read, lane l <- tap l, and hands them to the scalar side with
-    // v_readlane.  (Scalar loads straight from the tap-major plan -- one per tap, each in another cache line -- measured
-    // the same 39 us: what bounds the kernel is instruction issue, not those loads' latency.)
+    // Round 4 (late): every global load of the set-up is issued before the first LDS write that depends on one.  The first form
+    // staged chunk by chunk -- `if (inside) 16-byte load else byte-wise tail`, then the LDS write, per pass of a 4 x (1..4)-pass loop
+    // nest -- and the compiler put s_waitcnt vmcnt(0) behind each load: 4 to 16 memory round trips in a row per block, then two
+    // more for the weights and one for the bounds (tools/isa_loadwaits.py; SQ_WAIT_ANY was 51 % of the wave-cycles with neither
+    // the vector ALU nor the memory busy).  Now: the weights (two per thread) and the wave's column bounds first, then per pass over
+    // the chunk columns FOUR 16-byte loads (the thread's four rows) at addresses clamped into the image -- the one chunk that
+    // would cross the image's last byte is repaired afterwards under a branch that is hardly ever taken.
     const int opitch = cols + 4;                                               // (cols + 4) / 4 is odd: the lanes' result bytes fall in 64 banks
     uint8_t *s_out = lds + HW_ROWS * pitch;                                    // [3][HW_ROWS][opitch]
     int *s_w = reinterpret_cast<int *>(s_out + 3 * HW_ROWS * opitch);          // [cols][kp]
     const int ks = X.ksize, kp = ks | 1;
-    for (int i = tid; i < ks << lg; i += 256) {
+    const int n_w = ks << lg;
+    // the weights of the block's columns, transposed to [column][tap] (rows of an odd number of dwords): a wave then
+    // fetches one column's taps with ONE conflict-free read, lane l <- tap l, and hands them to the scalar side with
+    // v_readlane.  (Scalar loads straight from the tap-major plan -- one per tap, each in another cache line -- measured
+    // the same 39 us: what bounds the kernel is instruction issue, not those loads' latency.)
+    int wreg[2], wdst[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = min(tid + 256 * k, n_w - 1);
         const int t = i >> lg, xc = i & (cols - 1);
-        s_w[xc * kp + t] = X.kk[(unsigned)(t * X.out_w + min(xo0 + xc, X.out_w - 1))];
+        wdst[k] = xc * kp + t;
+        wreg[k] = X.kk[(unsigned)(t * X.out_w + min(xo0 + xc, X.out_w - 1))];
     }
     const int per = cols >> 2;
     const int xw0 = xo0 + wave * per;
-    int bx = 0, bn = 0;                                                        // lane j: the bounds of the wave's column j
-    if (lane < per && xw0 + lane < X.out_w) {
-        bx = X.bounds[2 * (xw0 + lane)];
-        bn = X.bounds[2 * (xw0 + lane) + 1];
+    const int bcol = min(xw0 + min(lane, per - 1), X.out_w - 1);               // lane j: the bounds of the wave's column j
+    int bx = X.bounds[2 * bcol], bn = X.bounds[2 * bcol + 1];
+    // 16 lanes per row, 16 rows per sweep (no division by run-time values anywhere in this kernel: an emulated integer
+    // division is ~40 vector instructions -- the first version spent more of them on its index arithmetic than on the taps)
+    if (total >= 16u) {
+        for (int ch = tid & 15; ch < nch; ch += 16) {
+            u32x4_t v[HW_ROWS / 16];
+            unsigned off[HW_ROWS / 16];
+#pragma unroll
+            for (int k = 0; k < HW_ROWS / 16; ++k) {
+                const int y = min(yb + (tid >> 4) + 16 * k, in_h - 1);
+                off[k] = (unsigned)y * (unsigned)J.in_stride + (unsigned)a0 + 16u * (unsigned)ch;
+                __builtin_memcpy(&v[k], J.src + min(off[k], total - 16u), 16);          // one unaligned global_load_dwordx4
+            }
+#pragma unroll
+            for (int k = 0; k < HW_ROWS / 16; ++k) {
+                if (off[k] + 16u > total) {                                            // the image's last bytes: nothing past them is read
+                    uint8_t b[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) b[e] = off[k] + e < total ? J.src[off[k] + e] : 0;
+                    __builtin_memcpy(&v[k], b, 16);
+                }
+                unsigned *d = reinterpret_cast<unsigned *>(lds + ((tid >> 4) + 16 * k) * pitch + 16 * ch);  // 4-byte aligned only: the pitch is 4 x odd
+                d[0] = v[k].x; d[1] = v[k].y; d[2] = v[k].z; d[3] = v[k].w;
+            }
+        }
+    } else {
+        for (int r = tid >> 4; r < HW_ROWS; r += 16) {                         // an image of fewer than 16 bytes
+            const unsigned row_off = (unsigned)min(yb + r, in_h - 1) * (unsigned)J.in_stride + (unsigned)a0;
+            for (int ch = tid & 15; ch < nch; ch += 16) {
+                const unsigned off = row_off + 16u * (unsigned)ch;
+                for (int e = 0; e < 16; ++e) lds[r * pitch + 16 * ch + e] = off + e < total ? J.src[off + e] : 0;
+            }
+        }
     }
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+        if (tid + 256 * k < n_w) s_w[wdst[k]] = wreg[k];
+    for (int i = tid + 512; i < n_w; i += 256) {                               // (more than 512 weights per block: the widest filters)
+        const int t = i >> lg, xc = i & (cols - 1);
+        s_w[xc * kp + t] = X.kk[(unsigned)(t * X.out_w + min(xo0 + xc, X.out_w - 1))];
+    }
+    if (!(lane < per && xw0 + lane < X.out_w)) bx = bn = 0;
     __syncthreads();
     const int nper = min(per, X.out_w - xw0);                                  // wave-uniform (may be <= 0)
     for (int j = 0; j < nper; ++j) {

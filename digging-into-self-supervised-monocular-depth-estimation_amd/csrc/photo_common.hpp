@@ -126,4 +126,43 @@ MDX_DEV void load_plane_tile(float (*dst)[TX + 2 * HALO], const float *__restric
     }
 }
 
+// The same for NP planes at once, with EVERY load of the block issued before the first LDS write (the 64-wide body as 16-byte
+// loads, the halo columns as scalars; rows beyond the reflection ring are clamped onto it: loaded, never read).  One plane at
+// a time (load_plane_tile) each thread's load sits in its own exec-masked block with an s_waitcnt vmcnt(0) behind it: NP x 2
+// memory round trips one after the other (tools/isa_loadwaits.py).  `planes[p]` are wave-uniform pointers.
+template <int HALO, int NP>
+MDX_DEV void load_plane_tiles(float (*const (&dst)[NP])[TX + 2 * HALO], const float *const (&planes)[NP], int H, int W, int x0,
+                              int y0, int tid)
+{
+    constexpr int NYT = TY + 2 * HALO, NBODY = NYT * (TX / 4), NHALO = NYT * 2 * HALO;
+    static_assert(NBODY <= NT && NHALO <= NT, "one body quad and one halo pixel per thread");
+    const bool wide = ((W & 3) == 0) && (x0 + TX <= W);
+    if (!wide) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) load_plane_tile<HALO>(dst[p], planes[p], H, W, x0, y0, tid);
+        return;
+    }
+    const int bt = tid < NBODY ? tid : NBODY - 1, ht = tid < NHALO ? tid : NHALO - 1;       // (idle threads repeat a load)
+    const int bly = bt / (TX / 4), bj = bt - bly * (TX / 4);
+    const int hly = ht / (2 * HALO), he = ht - hly * (2 * HALO);
+    const int hlx = he < HALO ? he : TX + he;
+    const int bgy = min(max(y0 + bly - HALO, -1), H), hgy = min(max(y0 + hly - HALO, -1), H), hgx = min(max(x0 + hlx - HALO, -1), W);
+    const unsigned bo = (unsigned)(reflect(bgy, H) * W + x0 + 4 * bj), ho = (unsigned)(reflect(hgy, H) * W + reflect(hgx, W));
+    float4 bv[NP];
+    float hv[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        bv[p] = *reinterpret_cast<const float4 *>(&at32(planes[p], bo));
+        hv[p] = at32(planes[p], ho);
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        if (tid < NBODY) {
+            float *o = &dst[p][bly][HALO + 4 * bj];
+            o[0] = bv[p].x; o[1] = bv[p].y; o[2] = bv[p].z; o[3] = bv[p].w;
+        }
+        if (tid < NHALO) dst[p][hly][hlx] = hv[p];
+    }
+}
+
 }  // namespace mdx

@@ -82,14 +82,21 @@ __global__ __launch_bounds__(NT, S <= 2 ? 5 : (S == 3 ? 4 : 3)) void photometric
     const float *tgt_b = a.target + (size_t)b * 3 * HW;
     const bool automask = (d.flags & MDX_FLAG_AUTOMASK) != 0;      // off: only the target statistics are wanted
 
-#pragma unroll
-    for (int c = 0; c < 3; ++c) load_plane_tile<1>(s_t[c], tgt_b + c * HW, H, W, x0, y0, tid);
+    // every load of the block in flight before the first LDS write (photo_common.hpp, load_plane_tiles)
     if (automask) {
+        float (*dst[3 + 3 * S])[FX];
+        const float *planes[3 + 3 * S];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { dst[c] = s_t[c]; planes[c] = tgt_b + c * HW; }
 #pragma unroll
         for (int f = 0; f < S; ++f)
 #pragma unroll
-            for (int c = 0; c < 3; ++c)
-                load_plane_tile<1>(s_x[f][c], a.src.img[f] + ((size_t)b * 3 + c) * HW, H, W, x0, y0, tid);
+            for (int c = 0; c < 3; ++c) { dst[3 + 3 * f + c] = s_x[f][c]; planes[3 + 3 * f + c] = a.src.img[f] + ((size_t)b * 3 + c) * HW; }
+        load_plane_tiles<1, 3 + 3 * S>(dst, planes, H, W, x0, y0, tid);
+    } else {
+        float (*dst[3])[FX] = {s_t[0], s_t[1], s_t[2]};
+        const float *planes[3] = {tgt_b, tgt_b + HW, tgt_b + 2 * HW};
+        load_plane_tiles<1, 3>(dst, planes, H, W, x0, y0, tid);
     }
     __syncthreads();
 

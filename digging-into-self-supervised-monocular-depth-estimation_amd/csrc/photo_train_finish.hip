@@ -50,6 +50,30 @@ MDX_DEV void upsample_bwd_tile(const float *__restrict__ gout, int H, int W, flo
     const float *g = gout + (size_t)bc * H * W;
     // ---- stage the region: 16-byte loads where the four columns are inside the image, scalars at its edges ----
     const bool vec = (W & 3) == 0;
+    if (vec) {
+        // W % 4 == 0 and xs is a multiple of 4: a quad lies wholly inside the image or wholly outside.  Every quad of the thread
+        // is loaded UNCONDITIONALLY (address clamped into the image, zeros selected afterwards), all of them in flight before the
+        // first LDS write: with the load inside `if (inside)` each pass of the loop was one memory round trip -- up to seven
+        // in a row at R = 8 (tools/isa_loadwaits.py)
+        constexpr int NQ = NR * (NC / 4), NIT = (NQ + NT - 1) / NT;
+        float4 v[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int e = min(tid + it * NT, NQ - 1);
+            const int rr = e / (NC / 4), c4 = (e - rr * (NC / 4)) * 4;
+            const int yc = min(max(ys + rr, 0), H - 1), xc = min(max(xs + c4, 0), W - 4);
+            v[it] = *reinterpret_cast<const float4 *>(g + (size_t)yc * W + xc);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int e = tid + it * NT;
+            if (e >= NQ) break;
+            const int rr = e / (NC / 4), c4 = (e - rr * (NC / 4)) * 4;
+            const int y = ys + rr, x = xs + c4;
+            const bool inside = y >= 0 && y < H && x >= 0 && x < W;
+            *reinterpret_cast<float4 *>(s_g + rr * NC + c4) = inside ? v[it] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    } else
     for (int e = tid; e < NR * (NC / 4); e += NT) {
         const int rr = e / (NC / 4), c4 = (e - rr * (NC / 4)) * 4;
         const int y = ys + rr, x = xs + c4;

@@ -17,15 +17,6 @@
 
 namespace mdx {
 
-MDX_DEV float edge_weight(const float *__restrict__ c0, size_t hw, size_t i, size_t j)
-{
-    float a0 = fabsf(c0[i] - c0[j]);
-    float a1 = fabsf(c0[hw + i] - c0[hw + j]);
-    float a2 = fabsf(c0[2 * hw + i] - c0[2 * hw + j]);
-    const float g = ((a0 + a1) + a2) * (1.0f / 3.0f);
-    return __expf(-g);      // hardware exponential: the smoothness term carries a 1e-4 tolerance, no pinned order
-}
-
 constexpr int APPLY_PIX = 8 * NT;      // pixels of one image per block of the finishing pass
 
 MDX_DEV float sgn(float a, float b) { return (a > b) ? 1.f : ((a < b) ? -1.f : 0.f); }
@@ -47,6 +38,13 @@ MDX_DEV void store_partials(double sd, double sx, double sy, double dot, double 
     }
 }
 
+// Both forms of the main pass are BRANCH-FREE around their loads: a neighbour that does not exist (image border) is read at
+// the pixel's own address instead -- the difference is then exactly 0, so the edge contributes 0 to the sums and sgn() = 0 to
+// the gradient, no mask needed -- and a thread beyond the image repeats the last pixel with its results zeroed.  Round 4's
+// first version guarded every neighbour load with its own `if`: the compiler put each one into an exec-masked block with an
+// s_waitcnt vmcnt(0) behind it -- sixteen memory round trips one after the other per wave, 14.6 us of a wave's life for 436
+// vector instructions (SQ_WAVE_CYCLES / SQ_WAVES, profiles/r04_bench_kernel_pmc.txt), 23.7 us per launch.
+
 // main pass, one pixel per thread (any width / alignment)
 MDX_DEV void main_body(const float *__restrict__ disp, const float *__restrict__ color, int B, int h, int w,
                        float *__restrict__ G, double *__restrict__ part, int bx, int nbx, int b)
@@ -55,38 +53,36 @@ MDX_DEV void main_body(const float *__restrict__ disp, const float *__restrict__
     const float *d = disp + (size_t)b * hw;
     const float *c0 = color + (size_t)b * 3 * hw;
     const double Nx = (double)B * h * (w - 1), Ny = (double)B * (h - 1) * w;
-    double sd = 0.0, sx = 0.0, sy = 0.0, dot = 0.0;
-    const size_t i = (size_t)bx * NT + threadIdx.x;
-    if (i < hw) {
-        const int y = (int)((unsigned)i / (unsigned)w), x = (int)((unsigned)i % (unsigned)w);
-        const float inv_nx = 1.0f / (float)Nx, inv_ny = 1.0f / (float)Ny;
-        const float n0 = d[i];
-        float gacc = 0.f;
-        if (x + 1 < w) {
-            const float n1 = d[i + 1];
-            const float wg = edge_weight(c0, hw, i, i + 1);
-            sx = (double)(fabsf(n0 - n1) * wg);
-            gacc += sgn(n0, n1) * wg * inv_nx;
-        }
-        if (x > 0) gacc -= sgn(d[i - 1], n0) * edge_weight(c0, hw, i - 1, i) * inv_nx;
-        if (y + 1 < h) {
-            const float n1 = d[i + w];
-            const float wg = edge_weight(c0, hw, i, i + w);
-            sy = (double)(fabsf(n0 - n1) * wg);
-            gacc += sgn(n0, n1) * wg * inv_ny;
-        }
-        if (y > 0) gacc -= sgn(d[i - w], n0) * edge_weight(c0, hw, i - w, i) * inv_ny;
-        if (G) G[(size_t)b * hw + i] = gacc;
-        sd = (double)n0;
-        dot = (double)gacc * (double)n0;
+    const size_t i0 = (size_t)bx * NT + threadIdx.x;
+    const bool live = i0 < hw;
+    const size_t i = live ? i0 : hw - 1;
+    const int y = (int)((unsigned)i / (unsigned)w), x = (int)((unsigned)i % (unsigned)w);
+    const float inv_nx = 1.0f / (float)Nx, inv_ny = 1.0f / (float)Ny;
+    const size_t ir = x + 1 < w ? i + 1 : i, il = x > 0 ? i - 1 : i, id = y + 1 < h ? i + w : i, iu = y > 0 ? i - w : i;
+    const float n0 = d[i], nr = d[ir], nl = d[il], nd = d[id], nu = d[iu];
+    float gr = 0.f, gl = 0.f, gd = 0.f, gu = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float *p = c0 + (size_t)c * hw;
+        const float cc = p[i];
+        gr += fabsf(cc - p[ir]); gl += fabsf(p[il] - cc); gd += fabsf(cc - p[id]); gu += fabsf(p[iu] - cc);
     }
+    const float wr = __expf(-gr * (1.0f / 3.0f)), wl = __expf(-gl * (1.0f / 3.0f));      // hardware exponential: 1e-4 tolerance,
+    const float wd = __expf(-gd * (1.0f / 3.0f)), wu = __expf(-gu * (1.0f / 3.0f));      // no pinned order
+    float gacc = sgn(n0, nr) * wr * inv_nx;
+    gacc -= sgn(nl, n0) * wl * inv_nx;
+    gacc += sgn(n0, nd) * wd * inv_ny;
+    gacc -= sgn(nu, n0) * wu * inv_ny;
+    if (live && G) G[(size_t)b * hw + i] = gacc;
+    const double sd = live ? (double)n0 : 0.0, sx = live ? (double)(fabsf(n0 - nr) * wr) : 0.0;
+    const double sy = live ? (double)(fabsf(n0 - nd) * wd) : 0.0, dot = live ? (double)gacc * (double)n0 : 0.0;
     store_partials(sd, sx, sy, dot, part, b, nbx, bx);
 }
 
 // The same pass with FOUR consecutive pixels of a row per thread (w % 4 == 0): the rows y-1, y, y+1 of the disparity and
 // of the three colour planes come in as 16-byte loads plus the two columns either side (12 vector + 8 scalar loads for
 // four pixels instead of 80 scalar ones -- the one-pixel form is bound by load instructions: 30 us for 29 MB at scale 0),
-// and a horizontal edge weight is formed once for the two pixels it joins.
+// and a horizontal edge weight is formed once for the two pixels it joins.  All twenty loads are issued back to back.
 MDX_DEV void main_body4(const float *__restrict__ disp, const float *__restrict__ color, int B, int h, int w,
                         float *__restrict__ G, double *__restrict__ part, int bx, int nbx, int b)
 {
@@ -94,65 +90,65 @@ MDX_DEV void main_body4(const float *__restrict__ disp, const float *__restrict_
     const float *d = disp + (size_t)b * hw;
     const float *c0 = color + (size_t)b * 3 * hw;
     const double Nx = (double)B * h * (w - 1), Ny = (double)B * (h - 1) * w;
-    double sd = 0.0, sx = 0.0, sy = 0.0, dot = 0.0;
-    const unsigned q = (unsigned)bx * NT + threadIdx.x;          // quad index inside the image
-    const unsigned wq = (unsigned)w / 4;
-    if (q < (unsigned)h * wq) {
-        const int y = (int)(q / wq), x = (int)(q - (unsigned)y * wq) * 4;
-        const float inv_nx = 1.0f / (float)Nx, inv_ny = 1.0f / (float)Ny;
-        const size_t i = (size_t)y * w + x;
-        const bool up = y > 0, dn = y + 1 < h, lf = x > 0, rt = x + 4 < w;
-        // disparity: the row, its neighbours, the columns either side
-        const float4 dc = *reinterpret_cast<const float4 *>(d + i);
-        const float4 du = up ? *reinterpret_cast<const float4 *>(d + i - w) : dc;
-        const float4 dd = dn ? *reinterpret_cast<const float4 *>(d + i + w) : dc;
-        const float dl = lf ? d[i - 1] : 0.f, dr = rt ? d[i + 4] : 0.f;
-        const float n[6] = {dl, dc.x, dc.y, dc.z, dc.w, dr};
-        const float nu[4] = {du.x, du.y, du.z, du.w};
-        const float nd[4] = {dd.x, dd.y, dd.z, dd.w};
-        // edge weights exp(-mean_c |I_a - I_b|): five horizontal (x-1|x ... x+3|x+4), four up, four down
-        float gh[5] = {0, 0, 0, 0, 0}, gu[4] = {0, 0, 0, 0}, gd[4] = {0, 0, 0, 0};
+    const unsigned wq = (unsigned)w / 4, nq = (unsigned)h * wq;
+    const unsigned q0 = (unsigned)bx * NT + threadIdx.x;          // quad index inside the image
+    const bool live = q0 < nq;
+    const unsigned q = live ? q0 : nq - 1;
+    const int y = (int)(q / wq), x = (int)(q - (unsigned)y * wq) * 4;
+    const float inv_nx = 1.0f / (float)Nx, inv_ny = 1.0f / (float)Ny;
+    const size_t i = (size_t)y * w + x;
+    const size_t iu = y > 0 ? i - w : i, id = y + 1 < h ? i + w : i, il = x > 0 ? i - 1 : i, ir = x + 4 < w ? i + 4 : i + 3;
+    // disparity: the row, its neighbours, the columns either side
+    const float4 dc = *reinterpret_cast<const float4 *>(d + i);
+    const float4 du = *reinterpret_cast<const float4 *>(d + iu);
+    const float4 dd = *reinterpret_cast<const float4 *>(d + id);
+    const float n[6] = {d[il], dc.x, dc.y, dc.z, dc.w, d[ir]};
+    const float nu[4] = {du.x, du.y, du.z, du.w};
+    const float nd[4] = {dd.x, dd.y, dd.z, dd.w};
+    // edge weights exp(-mean_c |I_a - I_b|): five horizontal (x-1|x ... x+3|x+4), four up, four down
+    float4 cc[3], cu[3], cd[3];
+    float cl[3], cr[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float *p = c0 + (size_t)c * hw + i;
-            const float4 cc = *reinterpret_cast<const float4 *>(p);
-            const float4 cu = up ? *reinterpret_cast<const float4 *>(p - w) : cc;
-            const float4 cd = dn ? *reinterpret_cast<const float4 *>(p + w) : cc;
-            const float cl = lf ? p[-1] : cc.x, cr = rt ? p[4] : cc.w;
-            const float row[6] = {cl, cc.x, cc.y, cc.z, cc.w, cr};
-#pragma unroll
-            for (int k = 0; k < 5; ++k) gh[k] += fabsf(row[k] - row[k + 1]);
-            gu[0] += fabsf(cu.x - cc.x); gu[1] += fabsf(cu.y - cc.y); gu[2] += fabsf(cu.z - cc.z); gu[3] += fabsf(cu.w - cc.w);
-            gd[0] += fabsf(cc.x - cd.x); gd[1] += fabsf(cc.y - cd.y); gd[2] += fabsf(cc.z - cd.z); gd[3] += fabsf(cc.w - cd.w);
-        }
-        float wh[5], wu[4], wd[4];
-#pragma unroll
-        for (int k = 0; k < 5; ++k) wh[k] = __expf(-gh[k] * (1.0f / 3.0f));
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { wu[k] = __expf(-gu[k] * (1.0f / 3.0f)); wd[k] = __expf(-gd[k] * (1.0f / 3.0f)); }
-        float4 gout;
-        float *go = &gout.x;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float n0 = n[k + 1];
-            float gacc = 0.f;
-            if (k < 3 || rt) {                                   // edge to the right neighbour
-                const float n1 = n[k + 2];
-                sx += (double)(fabsf(n0 - n1) * wh[k + 1]);
-                gacc += sgn(n0, n1) * wh[k + 1] * inv_nx;
-            }
-            if (k > 0 || lf) gacc -= sgn(n[k], n0) * wh[k] * inv_nx;     // edge to the left neighbour
-            if (dn) {
-                sy += (double)(fabsf(n0 - nd[k]) * wd[k]);
-                gacc += sgn(n0, nd[k]) * wd[k] * inv_ny;
-            }
-            if (up) gacc -= sgn(nu[k], n0) * wu[k] * inv_ny;
-            go[k] = gacc;
-            sd += (double)n0;
-            dot += (double)gacc * (double)n0;
-        }
-        if (G) *reinterpret_cast<float4 *>(G + (size_t)b * hw + i) = gout;
+    for (int c = 0; c < 3; ++c) {
+        const float *p = c0 + (size_t)c * hw;
+        cc[c] = *reinterpret_cast<const float4 *>(p + i);
+        cu[c] = *reinterpret_cast<const float4 *>(p + iu);
+        cd[c] = *reinterpret_cast<const float4 *>(p + id);
+        cl[c] = p[il];
+        cr[c] = p[ir];
     }
+    float gh[5] = {0, 0, 0, 0, 0}, gu[4] = {0, 0, 0, 0}, gd[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float row[6] = {cl[c], cc[c].x, cc[c].y, cc[c].z, cc[c].w, cr[c]};
+#pragma unroll
+        for (int k = 0; k < 5; ++k) gh[k] += fabsf(row[k] - row[k + 1]);
+        gu[0] += fabsf(cu[c].x - cc[c].x); gu[1] += fabsf(cu[c].y - cc[c].y); gu[2] += fabsf(cu[c].z - cc[c].z); gu[3] += fabsf(cu[c].w - cc[c].w);
+        gd[0] += fabsf(cc[c].x - cd[c].x); gd[1] += fabsf(cc[c].y - cd[c].y); gd[2] += fabsf(cc[c].z - cd[c].z); gd[3] += fabsf(cc[c].w - cd[c].w);
+    }
+    float wh[5], wu[4], wd[4];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) wh[k] = __expf(-gh[k] * (1.0f / 3.0f));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { wu[k] = __expf(-gu[k] * (1.0f / 3.0f)); wd[k] = __expf(-gd[k] * (1.0f / 3.0f)); }
+    float4 gout;
+    float *go = &gout.x;
+    double sd = 0.0, sx = 0.0, sy = 0.0, dot = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float n0 = n[k + 1], n1 = n[k + 2];
+        sx += (double)(fabsf(n0 - n1) * wh[k + 1]);                 // edge to the right neighbour
+        float gacc = sgn(n0, n1) * wh[k + 1] * inv_nx;
+        gacc -= sgn(n[k], n0) * wh[k] * inv_nx;                    // edge to the left neighbour
+        sy += (double)(fabsf(n0 - nd[k]) * wd[k]);
+        gacc += sgn(n0, nd[k]) * wd[k] * inv_ny;
+        gacc -= sgn(nu[k], n0) * wu[k] * inv_ny;
+        go[k] = gacc;
+        sd += (double)n0;
+        dot += (double)gacc * (double)n0;
+    }
+    if (live && G) *reinterpret_cast<float4 *>(G + (size_t)b * hw + i) = gout;
+    if (!live) sd = sx = sy = dot = 0.0;
     store_partials(sd, sx, sy, dot, part, b, nbx, bx);
 }
 
