@@ -34,10 +34,12 @@ constexpr int IMG_PLANS = 16;                // distinct (size -> size) plans pe
 constexpr int IMG_JOBS = MDX_IMG_JOBS;       // jobs per launch (72)
 struct PlanX {
     const int *bounds, *kk;                  // [out_w][2], [ksize][out_w]
-    int in_w, out_w, ksize;
-    uint8_t lg_cols;                         // rows form: log2(output columns per block); HW_GATHER = gather form
-    uint8_t pad;
+    const int *kc;                           // rows form: mdx_resample_plan_cols table [2][out_w][kc_row]
+    uint16_t in_w, out_w, ksize;             // (sizes <= 16384: validate_resample)
     uint16_t pitch;                          // rows form: LDS row pitch in bytes (4 x an odd number)
+    uint16_t kc_lead, kc_row;
+    uint8_t lg_cols;                         // rows form: log2(output columns per block); HW_GATHER = gather form
+    uint8_t pad[3];
 };
 struct PlanY {
     const int *bounds, *kk;                  // [out_h][2], [ksize][out_h]
@@ -55,7 +57,7 @@ struct ResampleLaunch {
     PlanY y[IMG_PLANS];
     PackedJob j[IMG_JOBS];
 };
-static_assert(sizeof(PlanX) == 32 && sizeof(PlanY) == 32 && sizeof(PackedJob) == 40, "packed launch layout");
+static_assert(sizeof(PlanX) == 40 && sizeof(PlanY) == 32 && sizeof(PackedJob) == 40, "packed launch layout");
 static_assert(sizeof(ResampleLaunch) <= 4096, "kernel arguments are limited to 4 KB");
 constexpr int JOB_FLIP = 1, JOB_VEC4 = 2, JOB_VEC8 = 4;
 constexpr int HW_GATHER = 255;
@@ -202,13 +204,19 @@ __global__ __launch_bounds__(256) void resample_h_kernel(ResampleLaunch L)
 // the mirrored span and take a column's weights in reverse order.  One launch serves every filter width (the tap loop is
 // wave-uniform).  Measured (rocprofv3, 32 / 12 KITTI frames 1242x375, us): 640 columns (13 taps) 38 against 46.5 for the
 // staged form; 320 (25 taps) 20.6 against 28.2 (gather); 160 (49 taps) 20 against 34 (staged); 80 (95 taps) 22 against 31
-// (taps along the lanes).  Its bound is the vector ALU and the LDS together: per column and wave 39 multiply-adds, 13
-// v_readlane (8 cycles each) and ~25 instructions of bookkeeping against 43 LDS instructions.
+// (taps along the lanes).  Its bound is the vector ALU and the LDS together (per column and wave 39 multiply-adds, 13
+// v_readlane of 8 cycles each and ~25 instructions of bookkeeping against 43 LDS instructions in that first form; see
+// hw_taps below for what round 4 made of the tap loop).
 constexpr int HW_ROWS = 64;
+#ifndef MDX_HW_ROWT
+#define MDX_HW_ROWT 1
+#endif
+constexpr int HW_ROWT = MDX_HW_ROWT;        // 64-row tiles per block, one after the other (A/B builds: -DMDX_HW_ROWT=2 ...)
 constexpr int HW_LDS_BUDGET = 40 * 1024;    // preferred LDS per block (4 blocks = 16 waves per CU)
 constexpr int HW_LDS_MAX = 64 * 1024;       // a 4-column block may take this much; beyond it the job keeps the gather form
 typedef volatile uint8_t __attribute__((address_space(3))) *lds_v_u8;
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef int i32x16_t __attribute__((ext_vector_type(16)));
 // a * w + c with a, w in 24 bits (|weight| < 2^22, byte < 2^8): ONE instruction, the weight in a scalar register.  Written
 // as asm because the compiler forms v_mad_i32_i24 from __mul24 + add in a few places only.
 static __device__ __forceinline__ int mad24s(int a, int w, int c)
@@ -217,6 +225,47 @@ static __device__ __forceinline__ int mad24s(int a, int w, int c)
     asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(w), "v"(c));
     return d;
 }
+// sixteen consecutive weights of a column's row of the column-major table, through the scalar cache (any dword alignment:
+// tools/smem_test.hip).  The compiler does not see the load: the wait is part of the statement.
+static __device__ __forceinline__ i32x16_t sload16(const int *p)
+{
+    i32x16_t v;
+    asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p));
+    return v;
+}
+
+// Round 4 (late): TWO neighbouring columns per pass, weights in scalar registers.  The windows of neighbouring output columns
+// overlap almost entirely (1242 -> 640: 13 taps, 1.94 pixels apart), so a wave that evaluates them together over the UNION of
+// the two windows reads each source byte once for both: per column 24 byte reads instead of 39 at 13 taps.  The weights come
+// as sixteen consecutive entries of the column's row of the column-major table (mdx_resample_plan_cols: zero-padded on both
+// sides, so the second column's row is simply read at an offset and taps outside a window multiply by 0) with ONE scalar load
+// per column and sixteen union pixels -- no LDS weight table, no v_readlane (8.5 cycles each, a quarter of the tap loop's
+// vector-ALU time), no weights in the set-up.  Flipped images: the union runs over the mirrored windows with the reversed rows
+// (table direction 1).  Exact integer sums: the order of the taps is free.
+template <bool PAIR>
+static __device__ __forceinline__ void hw_taps(lds_v_u8 q, const int *rf, const int *rs, int U, int (&sf)[3], int (&ss)[3])
+{
+    for (int c0 = 0; c0 < U; c0 += 16, q += 48) {
+        const i32x16_t wf = sload16(rf + c0);
+        i32x16_t ws = wf;
+        if (PAIR) ws = sload16(rs + c0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (c0 + 4 * g >= U) break;                                        // wave-uniform
+            int b[12];
+#pragma unroll
+            for (int e = 0; e < 12; ++e) b[e] = (int)q[12 * g + e];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    sf[c] = mad24s(b[3 * t + c], wf[4 * g + t], sf[c]);
+                    if (PAIR) ss[c] = mad24s(b[3 * t + c], ws[4 * g + t], ss[c]);
+                }
+            }
+        }
+    }
+}
 
 template <bool FLIP>
 static __device__ __forceinline__ void resample_h_rows(const PackedJob &J, const PlanX &X, int in_h, uint8_t *lds)
@@ -224,8 +273,8 @@ static __device__ __forceinline__ void resample_h_rows(const PackedJob &J, const
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lg = X.lg_cols, cols = 1 << lg, pitch = X.pitch;
-    const int xo0 = blockIdx.x << lg, yb = blockIdx.y * HW_ROWS;
-    const int xl = min(xo0 + cols, X.out_w) - 1;
+    const int xo0 = blockIdx.x << lg;
+    const int xl = min(xo0 + cols, (int)X.out_w) - 1;
     const int last = X.in_w - 1;
     // first / last source pixel the block's columns tap (bounds are monotonic in the column)
     const int lo_min = X.bounds[2 * xo0], hi_max = X.bounds[2 * xl] + X.bounds[2 * xl + 1] - 1;
@@ -233,114 +282,120 @@ static __device__ __forceinline__ void resample_h_rows(const PackedJob &J, const
     const int a0 = (3 * px_lo) & ~15;
     const int nch = min((3 * px_hi + 3 - a0 + 15) >> 4, (pitch - 12) >> 4);
     const unsigned total = (unsigned)in_h * (unsigned)J.in_stride;            // bytes of the image's rows (its slot may be larger)
-    // Round 4 (late): every global load of the set-up is issued before the first LDS write that depends on one.  The first form
-    // staged chunk by chunk -- `if (inside) 16-byte load else byte-wise tail`, then the LDS write, per pass of a 4 x (1..4)-pass loop
-    // nest -- and the compiler put s_waitcnt vmcnt(0) behind each load: 4 to 16 memory round trips in a row per block, then two
-    // more for the weights and one for the bounds (tools/isa_loadwaits.py; SQ_WAIT_ANY was 51 % of the wave-cycles with neither
-    // the vector ALU nor the memory busy).  Now: the weights (two per thread) and the wave's column bounds first, then per pass over
-    // the chunk columns FOUR 16-byte loads (the thread's four rows) at addresses clamped into the image -- the one chunk that
-    // would cross the image's last byte is repaired afterwards under a branch that is hardly ever taken.
+    // Every global load of the set-up is issued before the first LDS write that depends on one.  The first form staged chunk by
+    // chunk -- `if (inside) 16-byte load else byte-wise tail`, then the LDS write, per pass of a 4 x (1..4)-pass loop nest -- and
+    // the compiler put s_waitcnt vmcnt(0) behind each load: 4 to 16 memory round trips in a row per block
+    // (tools/isa_loadwaits.py; SQ_WAIT_ANY was 51 % of the wave-cycles with neither the vector ALU nor the memory busy).  Now: the
+    // wave's column bounds first, then per pass over the chunk columns FOUR 16-byte loads (the thread's four rows) at addresses
+    // clamped into the image -- the one chunk that would cross the image's last byte is repaired afterwards under a branch that
+    // is hardly ever taken.
     const int opitch = cols + 4;                                               // (cols + 4) / 4 is odd: the lanes' result bytes fall in 64 banks
     uint8_t *s_out = lds + HW_ROWS * pitch;                                    // [3][HW_ROWS][opitch]
-    int *s_w = reinterpret_cast<int *>(s_out + 3 * HW_ROWS * opitch);          // [cols][kp]
-    const int ks = X.ksize, kp = ks | 1;
-    const int n_w = ks << lg;
-    // the weights of the block's columns, transposed to [column][tap] (rows of an odd number of dwords): a wave then
-    // fetches one column's taps with ONE conflict-free read, lane l <- tap l, and hands them to the scalar side with
-    // v_readlane.  (Scalar loads straight from the tap-major plan -- one per tap, each in another cache line -- measured
-    // the same 39 us: what bounds the kernel is instruction issue, not those loads' latency.)
-    int wreg[2], wdst[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int i = min(tid + 256 * k, n_w - 1);
-        const int t = i >> lg, xc = i & (cols - 1);
-        wdst[k] = xc * kp + t;
-        wreg[k] = X.kk[(unsigned)(t * X.out_w + min(xo0 + xc, X.out_w - 1))];
-    }
     const int per = cols >> 2;
     const int xw0 = xo0 + wave * per;
-    const int bcol = min(xw0 + min(lane, per - 1), X.out_w - 1);               // lane j: the bounds of the wave's column j
-    int bx = X.bounds[2 * bcol], bn = X.bounds[2 * bcol + 1];
-    // 16 lanes per row, 16 rows per sweep (no division by run-time values anywhere in this kernel: an emulated integer
-    // division is ~40 vector instructions -- the first version spent more of them on its index arithmetic than on the taps)
-    if (total >= 16u) {
-        for (int ch = tid & 15; ch < nch; ch += 16) {
-            u32x4_t v[HW_ROWS / 16];
-            unsigned off[HW_ROWS / 16];
-#pragma unroll
-            for (int k = 0; k < HW_ROWS / 16; ++k) {
-                const int y = min(yb + (tid >> 4) + 16 * k, in_h - 1);
-                off[k] = (unsigned)y * (unsigned)J.in_stride + (unsigned)a0 + 16u * (unsigned)ch;
-                __builtin_memcpy(&v[k], J.src + min(off[k], total - 16u), 16);          // one unaligned global_load_dwordx4
-            }
-#pragma unroll
-            for (int k = 0; k < HW_ROWS / 16; ++k) {
-                if (off[k] + 16u > total) {                                            // the image's last bytes: nothing past them is read
-                    uint8_t b[16];
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) b[e] = off[k] + e < total ? J.src[off[k] + e] : 0;
-                    __builtin_memcpy(&v[k], b, 16);
-                }
-                unsigned *d = reinterpret_cast<unsigned *>(lds + ((tid >> 4) + 16 * k) * pitch + 16 * ch);  // 4-byte aligned only: the pitch is 4 x odd
-                d[0] = v[k].x; d[1] = v[k].y; d[2] = v[k].z; d[3] = v[k].w;
-            }
-        }
-    } else {
-        for (int r = tid >> 4; r < HW_ROWS; r += 16) {                         // an image of fewer than 16 bytes
-            const unsigned row_off = (unsigned)min(yb + r, in_h - 1) * (unsigned)J.in_stride + (unsigned)a0;
-            for (int ch = tid & 15; ch < nch; ch += 16) {
-                const unsigned off = row_off + 16u * (unsigned)ch;
-                for (int e = 0; e < 16; ++e) lds[r * pitch + 16 * ch + e] = off + e < total ? J.src[off + e] : 0;
-            }
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 2; ++k)
-        if (tid + 256 * k < n_w) s_w[wdst[k]] = wreg[k];
-    for (int i = tid + 512; i < n_w; i += 256) {                               // (more than 512 weights per block: the widest filters)
-        const int t = i >> lg, xc = i & (cols - 1);
-        s_w[xc * kp + t] = X.kk[(unsigned)(t * X.out_w + min(xo0 + xc, X.out_w - 1))];
-    }
-    if (!(lane < per && xw0 + lane < X.out_w)) bx = bn = 0;
-    __syncthreads();
-    const int nper = min(per, X.out_w - xw0);                                  // wave-uniform (may be <= 0)
-    for (int j = 0; j < nper; ++j) {
-        const int xc = wave * per + j;
-        const int xmin = __builtin_amdgcn_readlane(bx, j), n = __builtin_amdgcn_readlane(bn, j);
-        const int px0 = FLIP ? last - xmin - (n - 1) : xmin;
-        lds_v_u8 q = (lds_v_u8)(lds + lane * pitch + (3 * px0 - a0));
-        int s0 = 1 << (RS_BITS - 1), s1 = s0, s2 = s0;
-        for (int g = 0; g < n; g += 64) {                                      // 64 taps at a time (one pass up to 64 taps)
-            const int pos = g + lane;
-            const int wv = pos < n ? s_w[xc * kp + (FLIP ? n - 1 - pos : pos)] : 0;
-            const int ng = min(64, n - g);
-            int p = 0;
-            for (; p + 4 <= ng; p += 4, q += 12) {
-                int b[12];
-#pragma unroll
-                for (int e = 0; e < 12; ++e) b[e] = (int)q[e];
-                const int w0 = __builtin_amdgcn_readlane(wv, p), w1 = __builtin_amdgcn_readlane(wv, p + 1);
-                const int w2 = __builtin_amdgcn_readlane(wv, p + 2), w3 = __builtin_amdgcn_readlane(wv, p + 3);
-                s0 = mad24s(b[0], w0, s0); s1 = mad24s(b[1], w0, s1); s2 = mad24s(b[2], w0, s2);
-                s0 = mad24s(b[3], w1, s0); s1 = mad24s(b[4], w1, s1); s2 = mad24s(b[5], w1, s2);
-                s0 = mad24s(b[6], w2, s0); s1 = mad24s(b[7], w2, s1); s2 = mad24s(b[8], w2, s2);
-                s0 = mad24s(b[9], w3, s0); s1 = mad24s(b[10], w3, s1); s2 = mad24s(b[11], w3, s2);
-            }
-            for (; p < ng; ++p, q += 3) {
-                const int b0 = (int)q[0], b1 = (int)q[1], b2 = (int)q[2];
-                const int w = __builtin_amdgcn_readlane(wv, p);
-                s0 = mad24s(b0, w, s0);
-                s1 = mad24s(b1, w, s1);
-                s2 = mad24s(b2, w, s2);
-            }
-        }
-        s_out[(0 * HW_ROWS + lane) * opitch + xc] = clip8(s0);
-        s_out[(1 * HW_ROWS + lane) * opitch + xc] = clip8(s1);
-        s_out[(2 * HW_ROWS + lane) * opitch + xc] = clip8(s2);
-    }
-    __syncthreads();
+    const int bcol = min(xw0 + min(lane, per - 1), (int)X.out_w - 1);          // lane j: the bounds of the wave's column j
+    const int bx = X.bounds[2 * bcol], bn = X.bounds[2 * bcol + 1];
+    const int nper = min(per, (int)X.out_w - xw0);                             // wave-uniform (may be <= 0)
+    const int krow = X.kc_row, klead = X.kc_lead;
+    const int *ktab = X.kc + (FLIP ? (size_t)X.out_w * krow : 0) + klead;      // row of column x: ktab + x * krow
     const size_t plane = (size_t)in_h * X.out_w;
     const bool wide = (cols & 15) == 0 && (X.out_w & 15) == 0 && (((size_t)J.inter) & 15) == 0;
+    // A block walks HW_ROWT tiles of 64 rows one after the other (same columns: bounds, span and table rows are set up once).
+    // Measured twice, before and after the set-up's loads were batched (image preparation per batch, graph replay): 1 / 2 / 3 / 6
+    // tiles per block 141.9 / 143.7 / 143.5 / 148.4 us -- fewer, longer blocks buy nothing, so a block takes ONE tile; the loop
+    // stays for A/B builds.  (No barrier is needed between tiles: the staging of tile k + 1 writes the span rows, which every
+    // wave finished reading before the barrier in front of tile k's stores; its tap loop writes the result tile behind the
+    // barrier that follows the staging, i.e. after every wave's stores of tile k.)
+    // Phase switches of development builds: -DMDX_HW_NOSTAGE (no staging loads), -DMDX_HW_NOTAPS=n (at most n taps).  Per batch:
+    // block skeleton + stores 11 us, + staging 21 us (162 MB of spans through the L2: the source is re-read 3.2 x), + taps 44 us,
+    // all three 67 us: staging and taps overlap by 9 us only.  Loading tile k + 1's first two chunk columns into registers BEFORE
+    // tile k's tap loop and writing them to the span rows behind it (2 / 3 tiles per block) measured 146.1 / 141.4 us against
+    // 142.7 us: the 40 registers it holds across the tap loop cost the two resident blocks per CU that would have overlapped
+    // anyway (110 registers against 39).  Not kept.
+    // the four 16-byte loads of chunk column `ch` (the thread's four rows of tile yb) / their way into the span rows
+    auto stage_load = [&](int yb, int ch, u32x4_t (&v)[HW_ROWS / 16], unsigned (&off)[HW_ROWS / 16]) {
+#pragma unroll
+        for (int k = 0; k < HW_ROWS / 16; ++k) {
+            const int y = min(yb + (tid >> 4) + 16 * k, in_h - 1);
+            off[k] = (unsigned)y * (unsigned)J.in_stride + (unsigned)a0 + 16u * (unsigned)ch;
+            __builtin_memcpy(&v[k], J.src + min(off[k], total - 16u), 16);              // one unaligned global_load_dwordx4
+        }
+    };
+    auto stage_write = [&](int ch, u32x4_t (&v)[HW_ROWS / 16], const unsigned (&off)[HW_ROWS / 16]) {
+#pragma unroll
+        for (int k = 0; k < HW_ROWS / 16; ++k) {
+            if (off[k] + 16u > total) {
+                // the image's last bytes: the load was moved back to end at the last byte (nothing past it is read), the wanted
+                // bytes sit `sh` bytes further up in the 16 loaded ones: a 128-bit right shift, zeros coming in (never used)
+                const unsigned sh = min(off[k] + 16u - total, 16u) * 8u;                // 8 .. 128 bits
+                const unsigned long long lo = (unsigned long long)v[k].x | ((unsigned long long)v[k].y << 32);
+                const unsigned long long hi = (unsigned long long)v[k].z | ((unsigned long long)v[k].w << 32);
+                const unsigned long long nlo = sh >= 128u ? 0ull : (sh >= 64u ? hi >> (sh - 64u) : (lo >> sh) | (hi << (64u - sh)));
+                const unsigned long long nhi = sh >= 64u ? 0ull : hi >> sh;
+                v[k].x = (unsigned)nlo; v[k].y = (unsigned)(nlo >> 32); v[k].z = (unsigned)nhi; v[k].w = (unsigned)(nhi >> 32);
+            }
+            unsigned *d = reinterpret_cast<unsigned *>(lds + ((tid >> 4) + 16 * k) * pitch + 16 * ch);  // 4-byte aligned only: the pitch is 4 x odd
+            d[0] = v[k].x; d[1] = v[k].y; d[2] = v[k].z; d[3] = v[k].w;
+        }
+    };
+    // 16 lanes per row, 16 rows per sweep (no division by run-time values anywhere in this kernel: an emulated integer
+    // division is ~40 vector instructions -- the first version spent more of them on its index arithmetic than on the taps)
+    auto stage_tile = [&](int yb, int ch_first) {
+#ifndef MDX_HW_NOSTAGE
+        if (total >= 16u) {
+            for (int ch = ch_first; ch < nch; ch += 16) {
+                u32x4_t v[HW_ROWS / 16];
+                unsigned off[HW_ROWS / 16];
+                stage_load(yb, ch, v, off);
+                stage_write(ch, v, off);
+            }
+        } else if (ch_first < 16) {
+            for (int r = tid >> 4; r < HW_ROWS; r += 16) {                     // an image of fewer than 16 bytes
+                const unsigned row_off = (unsigned)min(yb + r, in_h - 1) * (unsigned)J.in_stride + (unsigned)a0;
+                for (int ch = tid & 15; ch < nch; ch += 16) {
+                    const unsigned off = row_off + 16u * (unsigned)ch;
+                    for (int e = 0; e < 16; ++e) lds[r * pitch + 16 * ch + e] = off + e < total ? J.src[off + e] : 0;
+                }
+            }
+        }
+#endif
+    };
+#pragma unroll 1
+    for (int rt = 0; rt < HW_ROWT; ++rt) {
+    const int yb = ((int)blockIdx.y * HW_ROWT + rt) * HW_ROWS;
+    if (yb >= in_h) break;                                                     // block-uniform
+    stage_tile(yb, tid & 15);
+    __syncthreads();
+    for (int j = 0; j < nper; j += 2) {
+        const bool pair = j + 1 < nper;
+        const int ja = j, jb = pair ? j + 1 : j;
+        const int xa = __builtin_amdgcn_readlane(bx, ja), na = __builtin_amdgcn_readlane(bn, ja);
+        const int xb = __builtin_amdgcn_readlane(bx, jb), nb = __builtin_amdgcn_readlane(bn, jb);
+        // window starts in the (mirrored, when flipped) source row.  Unflipped: column a starts first (bounds are monotonic);
+        // flipped: column b does.  `first` starts at p0, `second` d pixels later
+        const int pa = FLIP ? last - xa - (na - 1) : xa, pb = FLIP ? last - xb - (nb - 1) : xb;
+        const int p0 = FLIP ? pb : pa, d = FLIP ? pa - pb : pb - pa;
+        const int nf = FLIP ? nb : na, ns = FLIP ? na : nb;
+        const int cf = xw0 + (FLIP ? jb : ja), cs = xw0 + (FLIP ? ja : jb);
+        lds_v_u8 q = (lds_v_u8)(lds + lane * pitch + (3 * p0 - a0));
+        int sf[3] = {1 << (RS_BITS - 1), 1 << (RS_BITS - 1), 1 << (RS_BITS - 1)};
+        int ss[3] = {1 << (RS_BITS - 1), 1 << (RS_BITS - 1), 1 << (RS_BITS - 1)};
+        const int *rf = ktab + (size_t)cf * krow;
+#ifdef MDX_HW_NOTAPS
+        if (pair) hw_taps<true>(q, rf, ktab + (size_t)cs * krow - d, min(MDX_HW_NOTAPS, max(nf, d + ns)), sf, ss);
+        else hw_taps<false>(q, rf, rf, min(MDX_HW_NOTAPS, nf), sf, ss);
+#else
+        if (pair) hw_taps<true>(q, rf, ktab + (size_t)cs * krow - d, max(nf, d + ns), sf, ss);
+        else hw_taps<false>(q, rf, rf, nf, sf, ss);
+#endif
+        const int xcf = cf - xo0, xcs = cs - xo0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) s_out[(c * HW_ROWS + lane) * opitch + xcf] = clip8(sf[c]);
+        if (pair)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) s_out[(c * HW_ROWS + lane) * opitch + xcs] = clip8(ss[c]);
+    }
+    __syncthreads();
     if (wide) {                                                                // 16-byte row segments
         const int lgs = lg - 4;
         for (int i = tid; i < (3 * HW_ROWS) << lgs; i += 256) {
@@ -369,6 +424,7 @@ static __device__ __forceinline__ void resample_h_rows(const PackedJob &J, const
                 J.inter[pl * plane + (size_t)(yb + r) * X.out_w + xo0 + xc] = s_out[row * opitch + xc];
         }
     }
+    }   // rt
 }
 
 __global__ __launch_bounds__(256) void resample_h_rows_kernel(ResampleLaunch L)
@@ -378,7 +434,7 @@ __global__ __launch_bounds__(256) void resample_h_rows_kernel(ResampleLaunch L)
     const PlanX &X = L.x[J.px];
     if (X.lg_cols == HW_GATHER) return;
     const int in_h = L.y[J.py].in_h;
-    if ((int)(blockIdx.x << X.lg_cols) >= X.out_w || (int)blockIdx.y * HW_ROWS >= in_h) return;      // block-uniform
+    if ((int)(blockIdx.x << X.lg_cols) >= X.out_w || (int)blockIdx.y * HW_ROWS * HW_ROWT >= in_h) return;      // block-uniform
     if (J.flags & JOB_FLIP) resample_h_rows<true>(J, X, in_h, s_span);
     else resample_h_rows<false>(J, X, in_h, s_span);
 }
@@ -454,6 +510,7 @@ __global__ __launch_bounds__(256) void resample_v_kernel(ResampleLaunch L)
         for (int e = 0; e < 8; ++e) s[e] = 1 << (RS_BITS - 1);
         const size_t ps = (size_t)out_w, ksz = (size_t)out_h;
         int t = 0;
+        // (four taps per pass -- eight loads in flight instead of four -- measured the same: 142.7 against 142.1 us per batch)
         for (; t + 2 <= n; t += 2, p += 2 * ps, k += 2 * ksz) {
             const u32x2_t va = *reinterpret_cast<const u32x2_t *>(p), vb = *reinterpret_cast<const u32x2_t *>(p + ps);
             const int wa = k[0], wb = k[ksz];
@@ -827,6 +884,11 @@ static int validate_resample(const mdx_resample_job &J)
     if (J.dst_f32 && !aligned(J.dst_f32, 4)) return MDX_ERR_MISALIGNED;
     if (!aligned(J.xbounds, 4) || !aligned(J.xkk, 4) || !aligned(J.ybounds, 4) || !aligned(J.ykk, 4))
         return MDX_ERR_MISALIGNED;
+    if (J.xkc) {                       // column-major table (mdx_resample_plan_cols): shapes only, as for the plan itself
+        if (!aligned(J.xkc, 4)) return MDX_ERR_MISALIGNED;
+        if (J.xkc_lead < 0 || J.xkc_lead > 65535 || J.xkc_row > 65535 ||
+            J.xkc_row < J.xkc_lead + ((J.xksize + J.xkc_lead + 15) / 16) * 16 + 16) return MDX_ERR_BAD_SHAPE;
+    }
     return MDX_OK;
 }
 
@@ -877,6 +939,39 @@ MDX_EXPORT int mdx_resample_plan(int in_size, int out_size, int *bounds, int *kk
     return MDX_OK;
 }
 
+// The plan's weights column-major, zero-padded, both directions (include/mdx.h): what the rows form of the horizontal pass reads
+// with scalar loads.  HOST arrays.
+MDX_EXPORT int mdx_resample_plan_cols(int in_size, int out_size, int *lead_out, int *row_out, int *table)
+{
+    if (!lead_out || !row_out) return MDX_ERR_NULL_POINTER;
+    if (in_size <= 0 || out_size <= 0) return MDX_ERR_BAD_SHAPE;
+    const int ksize = ksize_of(in_size, out_size);
+    std::vector<int> bounds((size_t)out_size * 2), kk((size_t)ksize * out_size);
+    if (int rc = mdx_resample_plan(in_size, out_size, bounds.data(), kk.data())) return rc;
+    int lead = 0;
+    for (int x = 0; x + 1 < out_size; ++x) {
+        const int d0 = bounds[2 * x + 2] - bounds[2 * x];                                              // window starts
+        const int d1 = (bounds[2 * x + 2] + bounds[2 * x + 3]) - (bounds[2 * x] + bounds[2 * x + 1]);  // window ends (flipped: starts)
+        if (d0 < 0 || d1 < 0) return MDX_ERR_UNSUPPORTED;                                              // (Pillow's bounds are monotonic)
+        lead = d0 > lead ? d0 : lead;
+        lead = d1 > lead ? d1 : lead;
+    }
+    const int row = lead + ((ksize + lead + 15) / 16) * 16 + 16;
+    *lead_out = lead;
+    *row_out = row;
+    if (!table) return MDX_OK;
+    memset(table, 0, sizeof(int) * 2 * (size_t)out_size * row);
+    for (int x = 0; x < out_size; ++x) {
+        const int n = bounds[2 * x + 1];
+        int *f = table + (size_t)x * row + lead, *r = table + ((size_t)out_size + x) * row + lead;
+        for (int t = 0; t < n; ++t) {
+            f[t] = kk[(size_t)t * out_size + x];
+            r[t] = kk[(size_t)(n - 1 - t) * out_size + x];
+        }
+    }
+    return MDX_OK;
+}
+
 MDX_EXPORT int mdx_resample_lanczos_u8(const mdx_resample_job *jobs, int njobs, void *stream)
 {
     if (!jobs) return MDX_ERR_NULL_POINTER;
@@ -909,22 +1004,23 @@ MDX_EXPORT int mdx_resample_lanczos_u8(const mdx_resample_job *jobs, int njobs, 
         for (; first + n < njobs && n < IMG_JOBS; ++n) {
             const mdx_resample_job &S = jobs[order[first + n]];
             int ix = 0, iy = 0;
-            while (ix < nx && !(a.x[ix].bounds == S.xbounds && a.x[ix].kk == S.xkk && a.x[ix].in_w == S.in_w && a.x[ix].out_w == S.out_w)) ++ix;
+            while (ix < nx && !(a.x[ix].bounds == S.xbounds && a.x[ix].kk == S.xkk && a.x[ix].kc == S.xkc && a.x[ix].in_w == S.in_w && a.x[ix].out_w == S.out_w)) ++ix;
             while (iy < ny && !(a.y[iy].bounds == S.ybounds && a.y[iy].kk == S.ykk && a.y[iy].in_h == S.in_h && a.y[iy].out_h == S.out_h)) ++iy;
             if (ix == IMG_PLANS || iy == IMG_PLANS) break;          // a 17th plan: this job starts the next launch
             if (ix == nx) {
                 PlanX &X = a.x[nx++];
-                X.bounds = S.xbounds; X.kk = S.xkk; X.in_w = S.in_w; X.out_w = S.out_w; X.ksize = S.xksize;
+                X.bounds = S.xbounds; X.kk = S.xkk; X.in_w = (uint16_t)S.in_w; X.out_w = (uint16_t)S.out_w; X.ksize = (uint16_t)S.xksize;
+                X.kc = S.xkc; X.kc_lead = (uint16_t)S.xkc_lead; X.kc_row = (uint16_t)S.xkc_row;
                 // rows form: the widest block (64, 32, ... 4 columns) whose staged span + result tile + weights fit the LDS
                 // budget (measured on 1242 -> 640: 32 columns 38 us, 16 columns 45 us); gather form when even 4 do not fit
                 X.lg_cols = HW_GATHER;
                 const double scale = (double)S.in_w / S.out_w;
-                for (int lg = 6; lg >= 2 && !no_rows && X.lg_cols == HW_GATHER; --lg) {
+                for (int lg = 6; lg >= 2 && !no_rows && S.xkc && X.lg_cols == HW_GATHER; --lg) {
                     const int cw = 1 << lg;
                     if (cw > rows_cols_max) continue;
                     const int span_px = (int)ceil((cw - 1) * scale) + S.xksize + 2;
                     const int pitch = ((3 * span_px + 16 + 15) / 16) * 16 + 12;          // pitch / 4 is odd
-                    const int lds = HW_ROWS * pitch + 3 * HW_ROWS * (cw + 4) + 4 * cw * (S.xksize | 1);
+                    const int lds = HW_ROWS * pitch + 3 * HW_ROWS * (cw + 4);
                     if (lds <= rows_budget || (lg == 2 && lds <= HW_LDS_MAX)) {
                         X.lg_cols = (uint8_t)lg;
                         X.pitch = (uint16_t)pitch;
@@ -945,7 +1041,7 @@ MDX_EXPORT int mdx_resample_lanczos_u8(const mdx_resample_job *jobs, int njobs, 
             J.flags = (uint8_t)((S.flip ? JOB_FLIP : 0) | (vec4 ? JOB_VEC4 : 0) | (vec8 ? JOB_VEC8 : 0));
             if (X.lg_cols != HW_GATHER) {
                 const int cw = 1 << X.lg_cols;
-                const int lds = HW_ROWS * X.pitch + 3 * HW_ROWS * (cw + 4) + 4 * cw * (S.xksize | 1);
+                const int lds = HW_ROWS * X.pitch + 3 * HW_ROWS * (cw + 4);
                 rows_lds = lds > rows_lds ? lds : rows_lds;
                 const int gx = (S.out_w + cw - 1) / cw;
                 rows_gx = gx > rows_gx ? gx : rows_gx;
@@ -967,7 +1063,7 @@ MDX_EXPORT int mdx_resample_lanczos_u8(const mdx_resample_job *jobs, int njobs, 
             }
         }
         if (n_rows)
-            hipLaunchKernelGGL(resample_h_rows_kernel, dim3(rows_gx, (max_in_h + HW_ROWS - 1) / HW_ROWS, n), dim3(256),
+            hipLaunchKernelGGL(resample_h_rows_kernel, dim3(rows_gx, (max_in_h + HW_ROWS * HW_ROWT - 1) / (HW_ROWS * HW_ROWT), n), dim3(256),
                                (size_t)rows_lds, st, a);
         if (n_rows < n)
             hipLaunchKernelGGL(resample_h_kernel, dim3((gather_w + 63) / 64, (max_in_h + 4 * HR - 1) / (4 * HR), n), dim3(256), 0, st, a);

@@ -63,7 +63,8 @@ SYMBOLS = {
     "mdx_photometric_train": C.c_int, "mdx_photometric_prologue": C.c_int, "mdx_photometric_train_pre": C.c_int,
     "mdx_smooth_multi_workspace_bytes": C.c_size_t, "mdx_smooth_loss_multi": C.c_int,
     "mdx_depth_monitor_workspace_bytes": C.c_size_t, "mdx_depth_monitor": C.c_int,
-    "mdx_resample_ksize": C.c_int, "mdx_resample_plan": C.c_int, "mdx_resample_lanczos_u8": C.c_int,
+    "mdx_resample_ksize": C.c_int, "mdx_resample_plan": C.c_int, "mdx_resample_plan_cols": C.c_int,
+    "mdx_resample_lanczos_u8": C.c_int,
     "mdx_color_jitter_u8": C.c_int, "mdx_color_convert_u8": C.c_int, "mdx_to_tensor_u8": C.c_int,
 }
 

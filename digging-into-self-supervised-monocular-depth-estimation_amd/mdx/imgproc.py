@@ -29,11 +29,12 @@ JITTER_PARTIALS = 128      # MDX_JITTER_PARTIALS
 RESAMPLE_JOB = np.dtype([("src", "<u8"), ("xbounds", "<u8"), ("xkk", "<u8"), ("ybounds", "<u8"), ("ykk", "<u8"),
                          ("inter", "<u8"), ("dst_u8", "<u8"), ("dst_f32", "<u8"),
                          ("in_h", "<i4"), ("in_w", "<i4"), ("in_stride", "<i4"), ("flip", "<i4"),
-                         ("out_h", "<i4"), ("out_w", "<i4"), ("xksize", "<i4"), ("yksize", "<i4")])
+                         ("out_h", "<i4"), ("out_w", "<i4"), ("xksize", "<i4"), ("yksize", "<i4"),
+                         ("xkc", "<u8"), ("xkc_lead", "<i4"), ("xkc_row", "<i4")])
 JITTER_JOB = np.dtype([("src", "<u8"), ("dst_f32", "<u8"), ("dst_u8", "<u8"), ("lsum", "<u8"),
                        ("h", "<i4"), ("w", "<i4"), ("order", "<i4", (4,)), ("hue_shift", "<i4"),
                        ("brightness", "<f4"), ("contrast", "<f4"), ("saturation", "<f4")])
-assert RESAMPLE_JOB.itemsize == 96 and JITTER_JOB.itemsize == 72
+assert RESAMPLE_JOB.itemsize == 112 and JITTER_JOB.itemsize == 72
 
 
 def _check_u8(t, what):
@@ -44,8 +45,9 @@ class plan_cache(object):
     """Lanczos plans (Resample.c precompute_coeffs) per (in_size, out_size): built on the host by the library, kept on
     the device.  KITTI raw has five image sizes, so a run holds ~40 small tables."""
 
-    def __init__(self, device):
-        self.device, self.plans = device, {}
+    def __init__(self, device, cols=True):
+        # cols = False withholds the column-major weight table: the horizontal pass then runs in its gather form (tests)
+        self.device, self.plans, self.cols = device, {}, cols
 
     def get(self, in_size, out_size):
         key = (int(in_size), int(out_size))
@@ -59,8 +61,17 @@ class plan_cache(object):
             _lib.check(lib.mdx_resample_plan(key[0], key[1], bounds.ctypes.data_as(C.c_void_p),
                                              kk.ctypes.data_as(C.c_void_p)), "mdx_resample_plan")
             tb, tk = torch.from_numpy(bounds).to(self.device), torch.from_numpy(kk).to(self.device)
-            # (ksize, bounds, kk, their device addresses): a batch asks for ~150 of these, data_ptr() is not free
-            self.plans[key] = (ksize, tb, tk, tb.data_ptr(), tk.data_ptr())
+            # the same weights column-major, zero-padded, both directions: what the rows form of the horizontal pass reads
+            # with scalar loads (include/mdx.h, mdx_resample_plan_cols)
+            lead, row = C.c_int(0), C.c_int(0)
+            _lib.check(lib.mdx_resample_plan_cols(key[0], key[1], C.byref(lead), C.byref(row), None), "mdx_resample_plan_cols")
+            kc = np.zeros((2, key[1], row.value), np.int32)
+            _lib.check(lib.mdx_resample_plan_cols(key[0], key[1], C.byref(lead), C.byref(row),
+                                                  kc.ctypes.data_as(C.c_void_p)), "mdx_resample_plan_cols")
+            tc = torch.from_numpy(kc).to(self.device)
+            # (ksize, bounds, kk, their device addresses, kc + its address and geometry): a batch asks for ~150 of these,
+            # data_ptr() is not free
+            self.plans[key] = (ksize, tb, tk, tb.data_ptr(), tk.data_ptr(), tc, tc.data_ptr() if self.cols else 0, lead.value, row.value)
             # a plan outlives the call and may next be used from another stream (prefetcher / step): finish its upload now
             torch.cuda.current_stream(self.device).synchronize()
         return self.plans[key]
@@ -125,9 +136,10 @@ def resize_lanczos_multi(plans, sources, sizes, flips, outs):
     jobs["in_stride"], jobs["out_h"], jobs["out_w"] = c[:, 8:9], c[:, 9:10], c[:, 10:11]
     jobs["in_h"], jobs["in_w"] = np.array(hl, np.int32)[None, :], np.array(wl, np.int32)[None, :]
     jobs["flip"] = np.array([int(bool(f)) for f in flips], np.int32)[None, :]
-    xa = np.array([[(p[3], p[4], p[0]) for p in row] for row in xpl], dtype=np.uint64)[:, winv]     # [O, N, 3]
+    xa = np.array([[(p[3], p[4], p[0], p[6], p[7], p[8]) for p in row] for row in xpl], dtype=np.uint64)[:, winv]     # [O, N, 6]
     ya = np.array([[(p[3], p[4], p[0]) for p in row] for row in ypl], dtype=np.uint64)[:, hinv]
     jobs["xbounds"], jobs["xkk"], jobs["xksize"] = xa[:, :, 0], xa[:, :, 1], xa[:, :, 2]
+    jobs["xkc"], jobs["xkc_lead"], jobs["xkc_row"] = xa[:, :, 3], xa[:, :, 4], xa[:, :, 5]
     jobs["ybounds"], jobs["ykk"], jobs["yksize"] = ya[:, :, 0], ya[:, :, 1], ya[:, :, 2]
     jobs = jobs.reshape(-1)
     _lib.check(_lib.lib().mdx_resample_lanczos_u8(jobs.ctypes.data_as(C.c_void_p), len(jobs), _lib.stream()),

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MDX_VERSION 400
+#define MDX_VERSION 401
 #define MDX_MAX_SRC 4
 #define MDX_MAX_SCALES 4
 
@@ -348,6 +348,14 @@ int mdx_resample_ksize(int in_size, int out_size);
  * kk [ksize][out_size] = 22-bit fixed-point weights, TAP-MAJOR (the transpose of Pillow's table, so that consecutive
  * outputs read consecutive weights).  HOST arrays (the caller uploads and caches them per size pair). */
 int mdx_resample_plan(int in_size, int out_size, int *bounds, int *kk);
+/* The same weights COLUMN-MAJOR for the rows form of the horizontal pass (round 4), which fetches a column's taps with scalar
+ * loads and evaluates two neighbouring columns over the union of their windows: table [2][out_size][row] ints -- direction 0:
+ * table[0][x][lead + t] = weight t of output x; direction 1 (flipped images): the weights of x in reverse order,
+ * table[1][x][lead + t] = weight (n_x - 1 - t); everything else 0.  lead >= the largest offset between the windows of two
+ * neighbouring outputs (either direction); row = lead + ksize + lead rounded up to 16, + 16: every 16-entry read of a pair's
+ * union stays inside a row.  Call with table == NULL for the sizes (*lead, *row); HOST arrays, uploaded and cached by the
+ * caller like the plan itself. */
+int mdx_resample_plan_cols(int in_size, int out_size, int *lead, int *row, int *table);
 
 typedef struct mdx_resample_job {
     const uint8_t *src;          /* interleaved RGB, rows of in_stride bytes (>= 3*in_w): the decoder's layout */
@@ -358,6 +366,8 @@ typedef struct mdx_resample_job {
     float *dst_f32;              /* planar [3][out_h][out_w] = u8 / 255 (ToTensor), or NULL */
     int in_h, in_w, in_stride, flip;   /* flip: resize image.transpose(FLIP_LEFT_RIGHT) */
     int out_h, out_w, xksize, yksize;
+    const int *xkc;              /* mdx_resample_plan_cols table of in_w -> out_w (device copy) or NULL: without it the */
+    int xkc_lead, xkc_row;       /* horizontal pass runs in its general gather form (slower, same bytes)              */
 } mdx_resample_job;
 /* Image.resize((out_w, out_h), Image.LANCZOS): horizontal pass to uint8, then vertical pass. */
 int mdx_resample_lanczos_u8(const mdx_resample_job *jobs, int njobs, void *stream);

@@ -95,6 +95,24 @@ def test_resize_filter_widths(G, IP):
             assert np.array_equal(a[n].cpu().numpy(), orc.resample_lanczos(imgs[n], out[0], out[1], flips[n]).transpose(2, 0, 1)), ((h, w), out, n)
 
 
+def test_resize_rows_form_equals_gather_form(G, IP):
+    """the horizontal pass's two forms on the same jobs: rows form (two columns per pass over the union of their windows,
+    weights by scalar loads from the column-major table) against the gather form (job without the table) -- byte for byte,
+    KITTI pyramid shapes and ragged ones, flipped and not, odd column counts (a lone last column per wave)."""
+    rng = np.random.default_rng(79)
+    rows, gather = IP.plan_cache("cuda:0"), IP.plan_cache("cuda:0", cols=False)
+    for (h, w), out in [((70, 1242), (36, 640)), ((70, 1242), (18, 320)), ((70, 1242), (9, 160)), ((70, 1242), (5, 80)),
+                        ((70, 1241), (11, 637)), ((33, 500), (20, 250)), ((33, 301), (20, 299)), ((12, 64), (12, 64)), ((9, 40), (9, 90))]:
+        imgs = [_natural(rng, h, w), _natural(rng, h - 3, w - 7)]
+        sizes, flips = [(h, w), (h - 3, w - 7)], [False, True]
+        src = torch.from_numpy(_stack(imgs)).cuda()
+        a = IP.resize_lanczos(rows, src, sizes, flips, out, want_u8=True)[0]
+        b = IP.resize_lanczos(gather, src, sizes, flips, out, want_u8=True)[0]
+        assert torch.equal(a, b), ((h, w), out)
+        for n in range(2):
+            assert np.array_equal(a[n].cpu().numpy(), orc.resample_lanczos(imgs[n], out[0], out[1], flips[n]).transpose(2, 0, 1)), ((h, w), out, n)
+
+
 def test_resize_wide_source(G, IP):
     """a source 350x wider than its output (2101 taps per column): beyond the rows form's LDS tile, the gather form."""
     rng = np.random.default_rng(77)

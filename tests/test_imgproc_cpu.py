@@ -98,6 +98,37 @@ def test_library_plan_function_equals_oracle_coefficients():
     assert lib.mdx_resample_ksize(0, 4) < 0 and lib.mdx_resample_plan(4, 4, None, None) < 0
 
 
+def test_library_column_major_plan():
+    """mdx_resample_plan_cols (include/mdx.h): the plan's weights column-major, zero-padded, forward and reversed -- what the rows
+    form of the horizontal pass reads with scalar loads, two neighbouring columns over the union of their windows."""
+    from mdx import _lib
+    lib = _lib.lib()
+    for (i, o) in ((1242, 640), (1242, 320), (1242, 160), (1242, 80), (1226, 320), (30, 60), (64, 64), (7, 1), (14000, 40)):
+        ks, bounds, kk = orc.resample_coeffs(i, o)                        # kk [out][ksize]
+        lead, row = C.c_int(-1), C.c_int(-1)
+        assert lib.mdx_resample_plan_cols(i, o, C.byref(lead), C.byref(row), None) == 0
+        lead, row = lead.value, row.value
+        xmin, n = bounds[:, 0].astype(np.int64), bounds[:, 1].astype(np.int64)
+        need = max([0] + list(np.diff(xmin)) + list(np.diff(xmin + n)))
+        assert lead == need and row == lead + (ks + lead + 15) // 16 * 16 + 16
+        tab = np.full((2, o, row), 12345, np.int32)
+        l2, r2 = C.c_int(0), C.c_int(0)
+        assert lib.mdx_resample_plan_cols(i, o, C.byref(l2), C.byref(r2), tab.ctypes.data_as(C.c_void_p)) == 0
+        assert (l2.value, r2.value) == (lead, row)
+        want = np.zeros_like(tab)
+        for x in range(o):
+            want[0, x, lead:lead + n[x]] = kk[x, :n[x]]
+            want[1, x, lead:lead + n[x]] = kk[x, :n[x]][::-1]
+        assert np.array_equal(tab, want), (i, o)
+        # what the kernel relies on: a pair's union, read in chunks of 16 from either row (the second at -d), stays inside a row
+        for x in range(o - 1):
+            d = int(xmin[x + 1] - xmin[x])
+            U = max(int(n[x]), d + int(n[x + 1]))
+            assert 0 <= lead - d and lead + (U + 15) // 16 * 16 <= row
+    assert lib.mdx_resample_plan_cols(0, 4, C.byref(C.c_int()), C.byref(C.c_int()), None) < 0
+    assert lib.mdx_resample_plan_cols(4, 4, None, None, None) < 0
+
+
 def test_unit_from_byte_sequence_is_the_ieee_quotient():
     """csrc/imgproc.hip unit_from_byte: q0 = b * rc, r = fma(-255, q0, b), q = fma(r, rc, q0) with rc = fl32(1 / 255) equals
     float32(b) / float32(255) for every byte -- checked in exact rational arithmetic (each fma rounds once)."""
