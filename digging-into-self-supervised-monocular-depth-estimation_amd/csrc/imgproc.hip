@@ -487,58 +487,73 @@ __global__ __launch_bounds__(256) void resample_v_kernel(ResampleLaunch L)
     const PlanY &Y = L.y[J.py];
     const int out_w = X.out_w, out_h = Y.out_h, in_h = Y.in_h;
     if (J.flags & JOB_VEC8) {                      // block-uniform
+        // Round 4 (late): a thread owns eight bytes of TWO neighbouring output rows.  Their windows overlap almost entirely (375 ->
+        // 192 rows: 13 taps, 1.95 rows apart), so the union is walked once -- 15 row loads for two rows instead of 26 -- and a
+        // launch has half the blocks: the pass was bound by blocks x (chain of dependent loads in front of a block's first tap),
+        // not by its arithmetic or its bytes.  Row a starts first (bounds are monotonic), row b `d` rows later; a tap outside a
+        // row's window gets weight 0 (the plan's table is zero beyond a row's taps; beyond the table the index is clamped and
+        // the weight selected to 0 -- no conditional load anywhere).
         const int tpr = out_w >> 3;                // threads per row
-        int xo, yo;
+        int xo, yp;
         if (tpr >= 256) {
             xo = (blockIdx.x * 256 + threadIdx.x) * 8;
-            yo = blockIdx.y;
+            yp = blockIdx.y;
         } else {
             if (blockIdx.x) return;
-            const int rpb = 256 / tpr;             // rows per block (block-uniform)
+            const int rpb = 256 / tpr;             // row PAIRS per block (block-uniform)
             const int r = threadIdx.x / tpr;
             xo = (threadIdx.x - r * tpr) * 8;
-            yo = blockIdx.y * rpb + r;
+            yp = blockIdx.y * rpb + r;
             if (r >= rpb) return;
         }
-        if (xo >= out_w || yo >= out_h) return;
-        const int ymin = Y.bounds[2 * yo], n = Y.bounds[2 * yo + 1];
-        const int *k = Y.kk + yo;                  // [ksize][out_h]
+        const int ya = 2 * yp;
+        if (xo >= out_w || ya >= out_h) return;
+        const bool two = ya + 1 < out_h;
+        const int yb = two ? ya + 1 : ya;
+        const int ymin = Y.bounds[2 * ya], na = Y.bounds[2 * ya + 1];
+        const int yminb = Y.bounds[2 * yb], nb = Y.bounds[2 * yb + 1];
+        const int d = yminb - ymin;
+        const int U = max(na, d + nb), ks = Y.ksize;
+        const int *ka = Y.kk + ya, *kb = Y.kk + yb; // [ksize][out_h]
         const uint8_t *p = J.inter + ((size_t)c * in_h + ymin) * out_w + xo;
-        const size_t o = ((size_t)c * out_h + yo) * out_w + xo;
-        int s[8];
+        const size_t o = ((size_t)c * out_h + ya) * out_w + xo;
+        int s[8], q[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s[e] = 1 << (RS_BITS - 1);
+        for (int e = 0; e < 8; ++e) s[e] = q[e] = 1 << (RS_BITS - 1);
         const size_t ps = (size_t)out_w, ksz = (size_t)out_h;
-        int t = 0;
-        // (four taps per pass -- eight loads in flight instead of four -- measured the same: 142.7 against 142.1 us per batch)
-        for (; t + 2 <= n; t += 2, p += 2 * ps, k += 2 * ksz) {
-            const u32x2_t va = *reinterpret_cast<const u32x2_t *>(p), vb = *reinterpret_cast<const u32x2_t *>(p + ps);
-            const int wa = k[0], wb = k[ksz];
-            s[0] = add3(s[0], mul_byte0(va.x, wa), mul_byte0(vb.x, wb));
-            s[1] = add3(s[1], mul_byte1(va.x, wa), mul_byte1(vb.x, wb));
-            s[2] = add3(s[2], mul_byte2(va.x, wa), mul_byte2(vb.x, wb));
-            s[3] = add3(s[3], mul_byte3(va.x, wa), mul_byte3(vb.x, wb));
-            s[4] = add3(s[4], mul_byte0(va.y, wa), mul_byte0(vb.y, wb));
-            s[5] = add3(s[5], mul_byte1(va.y, wa), mul_byte1(vb.y, wb));
-            s[6] = add3(s[6], mul_byte2(va.y, wa), mul_byte2(vb.y, wb));
-            s[7] = add3(s[7], mul_byte3(va.y, wa), mul_byte3(vb.y, wb));
+        const int last_row = in_h - 1 - ymin;      // union rows beyond the image (the pad of an odd union) are read at the last row, weight 0
+        for (int t = 0; t < U; t += 2) {
+            const u32x2_t va = *reinterpret_cast<const u32x2_t *>(p + (size_t)min(t, last_row) * ps);
+            const u32x2_t vb = *reinterpret_cast<const u32x2_t *>(p + (size_t)min(t + 1, last_row) * ps);
+            const int t1 = t + 1, u0 = t - d, u1 = t + 1 - d;
+            const int wa0r = ka[(size_t)min(t, ks - 1) * ksz], wa1r = ka[(size_t)min(t1, ks - 1) * ksz];
+            const int wb0r = kb[(size_t)min(max(u0, 0), ks - 1) * ksz], wb1r = kb[(size_t)min(max(u1, 0), ks - 1) * ksz];
+            const int wa0 = t < na ? wa0r : 0, wa1 = t1 < na ? wa1r : 0;
+            const int wb0 = (u0 >= 0 && u0 < nb) ? wb0r : 0, wb1 = (u1 >= 0 && u1 < nb) ? wb1r : 0;
+            s[0] = add3(s[0], mul_byte0(va.x, wa0), mul_byte0(vb.x, wa1)); q[0] = add3(q[0], mul_byte0(va.x, wb0), mul_byte0(vb.x, wb1));
+            s[1] = add3(s[1], mul_byte1(va.x, wa0), mul_byte1(vb.x, wa1)); q[1] = add3(q[1], mul_byte1(va.x, wb0), mul_byte1(vb.x, wb1));
+            s[2] = add3(s[2], mul_byte2(va.x, wa0), mul_byte2(vb.x, wa1)); q[2] = add3(q[2], mul_byte2(va.x, wb0), mul_byte2(vb.x, wb1));
+            s[3] = add3(s[3], mul_byte3(va.x, wa0), mul_byte3(vb.x, wa1)); q[3] = add3(q[3], mul_byte3(va.x, wb0), mul_byte3(vb.x, wb1));
+            s[4] = add3(s[4], mul_byte0(va.y, wa0), mul_byte0(vb.y, wa1)); q[4] = add3(q[4], mul_byte0(va.y, wb0), mul_byte0(vb.y, wb1));
+            s[5] = add3(s[5], mul_byte1(va.y, wa0), mul_byte1(vb.y, wa1)); q[5] = add3(q[5], mul_byte1(va.y, wb0), mul_byte1(vb.y, wb1));
+            s[6] = add3(s[6], mul_byte2(va.y, wa0), mul_byte2(vb.y, wa1)); q[6] = add3(q[6], mul_byte2(va.y, wb0), mul_byte2(vb.y, wb1));
+            s[7] = add3(s[7], mul_byte3(va.y, wa0), mul_byte3(vb.y, wa1)); q[7] = add3(q[7], mul_byte3(va.y, wb0), mul_byte3(vb.y, wb1));
         }
-        if (t < n) {
-            const u32x2_t va = *reinterpret_cast<const u32x2_t *>(p);
-            const int wa = k[0];
-            s[0] += mul_byte0(va.x, wa); s[1] += mul_byte1(va.x, wa); s[2] += mul_byte2(va.x, wa); s[3] += mul_byte3(va.x, wa);
-            s[4] += mul_byte0(va.y, wa); s[5] += mul_byte1(va.y, wa); s[6] += mul_byte2(va.y, wa); s[7] += mul_byte3(va.y, wa);
-        }
-        unsigned v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = clip8(s[e]);
-        if (J.dst_u8) {
-            u32x2_t pk = {v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24), v[4] | (v[5] << 8) | (v[6] << 16) | (v[7] << 24)};
-            *reinterpret_cast<u32x2_t *>(J.dst_u8 + o) = pk;
-        }
-        if (J.dst_f32) {
-            *reinterpret_cast<float4 *>(J.dst_f32 + o) = make_float4(unit_from_byte(v[0]), unit_from_byte(v[1]), unit_from_byte(v[2]), unit_from_byte(v[3]));
-            *reinterpret_cast<float4 *>(J.dst_f32 + o + 4) = make_float4(unit_from_byte(v[4]), unit_from_byte(v[5]), unit_from_byte(v[6]), unit_from_byte(v[7]));
+        for (int half = 0; half < 2; ++half) {
+            if (half && !two) break;
+            unsigned v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = clip8(half ? q[e] : s[e]);
+            const size_t oo = o + (half ? ps : 0);
+            if (J.dst_u8) {
+                u32x2_t pk = {v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24), v[4] | (v[5] << 8) | (v[6] << 16) | (v[7] << 24)};
+                *reinterpret_cast<u32x2_t *>(J.dst_u8 + oo) = pk;
+            }
+            if (J.dst_f32) {
+                *reinterpret_cast<float4 *>(J.dst_f32 + oo) = make_float4(unit_from_byte(v[0]), unit_from_byte(v[1]), unit_from_byte(v[2]), unit_from_byte(v[3]));
+                *reinterpret_cast<float4 *>(J.dst_f32 + oo + 4) = make_float4(unit_from_byte(v[4]), unit_from_byte(v[5]), unit_from_byte(v[6]), unit_from_byte(v[7]));
+            }
         }
     } else {
         const int xo = blockIdx.x * 256 + threadIdx.x;
@@ -1051,9 +1066,9 @@ MDX_EXPORT int mdx_resample_lanczos_u8(const mdx_resample_job *jobs, int njobs, 
             }
             max_in_h = S.in_h > max_in_h ? S.in_h : max_in_h;
             if (vec8) {
-                const int tpr = S.out_w / 8;
+                const int tpr = S.out_w / 8, pairs = (S.out_h + 1) / 2;     // a thread owns eight bytes of TWO rows
                 const int gx = tpr >= 256 ? (tpr + 255) / 256 : 1;
-                const int gy = tpr >= 256 ? S.out_h : (S.out_h + 256 / tpr - 1) / (256 / tpr);
+                const int gy = tpr >= 256 ? pairs : (pairs + 256 / tpr - 1) / (256 / tpr);
                 v8_gx = gx > v8_gx ? gx : v8_gx;
                 v8_gy = gy > v8_gy ? gy : v8_gy;
             } else {
