@@ -229,9 +229,16 @@ static __device__ __forceinline__ int mad24s(int a, int w, int c)
 // tools/smem_test.hip).  The compiler does not see the load: the wait is part of the statement.
 static __device__ __forceinline__ i32x16_t sload16(const int *p)
 {
+#ifdef MDX_HW_SLOAD_ASM
     i32x16_t v;
     asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p));
     return v;
+#else
+    // a uniform pointer into the CONSTANT address space: the compiler selects s_load_dwordx16 itself and accounts for it in its
+    // own s_waitcnt bookkeeping, so the load may stay in flight across the LDS reads that follow
+    typedef const i32x16_t __attribute__((address_space(4), aligned(4))) *cptr;
+    return *(cptr)(unsigned long long)p;
+#endif
 }
 
 // Round 4 (late): TWO neighbouring columns per pass, weights in scalar registers.  The windows of neighbouring output columns
