@@ -239,11 +239,16 @@ __global__ __launch_bounds__(NB) void bn_bwd_apply_kernel(const T *__restrict__ 
 // owns a channel, keeps its <= 24 elements per thread in registers between the reduction and the apply step, so the
 // activations cross HBM once (forward: read x [, identity], write y; backward: read dy, y, x, write dx [, d_identity]).
 // -----------------------------------------------------------------------------------------------------------
-constexpr int SB = 1024;                     // threads per block
+constexpr int SB = 1024;                     // threads per block (largest form)
+constexpr int SB_TINY = 256;                 // ... and for channels of at most 2 vectors per thread of this size (2048 elements).  Round 4:
+                                             // the 512-channel maps of a 192x640 batch (1440 elements per channel) fill 360 of a 1024-thread
+                                             // block's lanes and its reductions run over sixteen waves: forward 11.9 -> 7.2 us, backward
+                                             // 11.1 -> 7.3 us with 256 threads.  (The 256-channel maps, 5760 elements, are SLOWER that
+                                             // way -- 8.0 -> 9.0 / 9.8 -> 11.4 us with six vectors per thread -- and keep the large block.)
 constexpr int SV = 6;                        // 4-element vectors per thread
 constexpr int SMALL_MAX = SB * SV * VEC;     // 24576 elements per channel
 
-__device__ __forceinline__ float block_sum_1024(float v, float *lds)
+template <int NTH> __device__ __forceinline__ float block_sum_small(float v, float *lds)
 {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -251,29 +256,29 @@ __device__ __forceinline__ float block_sum_1024(float v, float *lds)
     __syncthreads();
     float t = 0.f;
 #pragma unroll
-    for (int k = 0; k < SB / 64; ++k) t += lds[k];
+    for (int k = 0; k < NTH / 64; ++k) t += lds[k];
     __syncthreads();
     return t;
 }
 
 // element offset (inside the [B,C,H,W] tensor) of vector j of this thread, or -1 beyond the channel's data
-__device__ __forceinline__ long long small_offset(int j, int c, int C, int HW, int M)
+template <int NTH> __device__ __forceinline__ long long small_offset(int j, int c, int C, int HW, int M)
 {
-    const int e = (j * SB + threadIdx.x) * VEC;       // linear index over (b, hw) of channel c
+    const int e = (j * NTH + threadIdx.x) * VEC;      // linear index over (b, hw) of channel c
     if (e >= M) return -1;
     const int b = e / HW, off = e - b * HW;
     return ((long long)b * C + c) * HW + off;
 }
 
-template <typename T>
-__global__ __launch_bounds__(SB) void bn_small_fwd_kernel(const float *__restrict__ gamma, const float *__restrict__ beta,
+template <typename T, int NTH>
+__global__ __launch_bounds__(NTH) void bn_small_fwd_kernel(const float *__restrict__ gamma, const float *__restrict__ beta,
                                                           int C, int HW, int B, float eps, float momentum, int relu,
                                                           T *__restrict__ y_all, float *__restrict__ save_mean_all,
                                                           float *__restrict__ save_invstd_all, float *__restrict__ run_mean,
                                                           float *__restrict__ run_var, const T *__restrict__ x_all,
                                                           const T *__restrict__ res_all, int G)
 {
-    __shared__ float lds[SB / 64];
+    __shared__ float lds[NTH / 64];
     const int c = blockIdx.x, M = B * HW;
     // G consecutive sub-batches of B images, one after the other: own statistics each, running statistics updated in
     // order (what G calls of the module do) -- from one launch
@@ -289,7 +294,7 @@ __global__ __launch_bounds__(SB) void bn_small_fwd_kernel(const float *__restric
     float a = 0.f;
 #pragma unroll
     for (int j = 0; j < SV; ++j) {
-        o[j] = small_offset(j, c, C, HW, M);
+        o[j] = small_offset<NTH>(j, c, C, HW, M);
         if (o[j] >= 0) v[j] = *reinterpret_cast<const Vec4<T> *>(x + o[j]);
     }
 #pragma unroll
@@ -297,14 +302,14 @@ __global__ __launch_bounds__(SB) void bn_small_fwd_kernel(const float *__restric
         if (o[j] >= 0)
 #pragma unroll
             for (int k = 0; k < VEC; ++k) a += ld(v[j].v, k);
-    const float mean = block_sum_1024(a, lds) / (float)M;
+    const float mean = block_sum_small<NTH>(a, lds) / (float)M;
     float q = 0.f;                                   // two-pass variance: the data is in registers
 #pragma unroll
     for (int j = 0; j < SV; ++j)
         if (o[j] >= 0)
 #pragma unroll
             for (int k = 0; k < VEC; ++k) { const float d = ld(v[j].v, k) - mean; q = __builtin_fmaf(d, d, q); }
-    const float var = block_sum_1024(q, lds) / (float)M;
+    const float var = block_sum_small<NTH>(q, lds) / (float)M;
     const float invstd = 1.0f / sqrtf(var + eps);
     if (threadIdx.x == 0) {
         save_mean[c] = mean;
@@ -333,8 +338,8 @@ __global__ __launch_bounds__(SB) void bn_small_fwd_kernel(const float *__restric
     }   // grp
 }
 
-template <typename T>
-__global__ __launch_bounds__(SB) void bn_small_bwd_kernel(const T *__restrict__ dy_all, const T *__restrict__ y_all,
+template <typename T, int NTH>
+__global__ __launch_bounds__(NTH) void bn_small_bwd_kernel(const T *__restrict__ dy_all, const T *__restrict__ y_all,
                                                           const T *__restrict__ x_all, const float *__restrict__ gamma,
                                                           const float *__restrict__ save_mean,
                                                           const float *__restrict__ save_invstd, int C, int HW, int B,
@@ -342,7 +347,7 @@ __global__ __launch_bounds__(SB) void bn_small_bwd_kernel(const T *__restrict__ 
                                                           T *__restrict__ dres_all, float *__restrict__ dgamma,
                                                           float *__restrict__ dbeta, int G)
 {
-    __shared__ float lds[SB / 64];
+    __shared__ float lds[NTH / 64];
     const int c = blockIdx.x, M = B * HW;
     float tot_a = 0.f, tot_q = 0.f;
 #pragma unroll 1
@@ -357,7 +362,7 @@ __global__ __launch_bounds__(SB) void bn_small_bwd_kernel(const T *__restrict__ 
     float a = 0.f, q = 0.f;
 #pragma unroll
     for (int j = 0; j < SV; ++j) {
-        o[j] = small_offset(j, c, C, HW, M);
+        o[j] = small_offset<NTH>(j, c, C, HW, M);
         if (o[j] < 0) continue;
         const Vec4<T> vd = *reinterpret_cast<const Vec4<T> *>(dy + o[j]);
         const Vec4<T> vy = *reinterpret_cast<const Vec4<T> *>(y + o[j]);
@@ -370,8 +375,8 @@ __global__ __launch_bounds__(SB) void bn_small_bwd_kernel(const T *__restrict__ 
             q = __builtin_fmaf(dz[j][k], xh[j][k], q);
         }
     }
-    a = block_sum_1024(a, lds);
-    q = block_sum_1024(q, lds);
+    a = block_sum_small<NTH>(a, lds);
+    q = block_sum_small<NTH>(q, lds);
     tot_a += a;
     tot_q += q;
     const float k0 = gamma[c] * invstd, mdz = a / (float)M, mdzx = q / (float)M;
@@ -394,6 +399,14 @@ __global__ __launch_bounds__(SB) void bn_small_bwd_kernel(const T *__restrict__ 
     }
 }
 
+// the small-map kernels in their 256- or 1024-thread form by the channel's element count
+#define MDX_BN_SMALL(kind, T, ...)                                                                                   \
+    do {                                                                                                             \
+        if ((long long)B * HW <= (long long)SB_TINY * 2 * VEC)                                                       \
+            hipLaunchKernelGGL((bn_small_##kind##_kernel<T, SB_TINY>), dim3(C), dim3(SB_TINY), 0, st, __VA_ARGS__);  \
+        else                                                                                                         \
+            hipLaunchKernelGGL((bn_small_##kind##_kernel<T, SB>), dim3(C), dim3(SB), 0, st, __VA_ARGS__);            \
+    } while (0)
 static inline bool small_map(int B, int HW) { return (HW % VEC) == 0 && (long long)B * HW <= SMALL_MAX; }
 
 static inline int spans_per_plane(int HW) { return (HW + SPAN - 1) / SPAN; }
@@ -424,11 +437,11 @@ MDX_EXPORT int mdx_bn_act_fwd(const void *x, const void *res, const float *gamma
     hipStream_t st = (hipStream_t)stream;
     if (small_map(B, HW)) {
         if (dtype == 0)
-            hipLaunchKernelGGL((bn_small_fwd_kernel<float>), dim3(C), dim3(SB), 0, st, gamma, beta, C, HW, B, eps, momentum,
+            MDX_BN_SMALL(fwd, float, gamma, beta, C, HW, B, eps, momentum,
                                relu, (float *)y, save_mean, save_invstd, run_mean, run_var, (const float *)x,
                                (const float *)res, groups);
         else
-            hipLaunchKernelGGL((bn_small_fwd_kernel<bf16n>), dim3(C), dim3(SB), 0, st, gamma, beta, C, HW, B, eps, momentum,
+            MDX_BN_SMALL(fwd, bf16n, gamma, beta, C, HW, B, eps, momentum,
                                relu, (bf16n *)y, save_mean, save_invstd, run_mean, run_var, (const bf16n *)x,
                                (const bf16n *)res, groups);
         return check_launch();
@@ -469,11 +482,11 @@ MDX_EXPORT int mdx_bn_act_bwd(const void *dy, const void *y, const void *x, cons
     hipStream_t st = (hipStream_t)stream;
     if (small_map(B, HW)) {
         if (dtype == 0)
-            hipLaunchKernelGGL((bn_small_bwd_kernel<float>), dim3(C), dim3(SB), 0, st, (const float *)dy, (const float *)y,
+            MDX_BN_SMALL(bwd, float, (const float *)dy, (const float *)y,
                                (const float *)x, gamma, save_mean, save_invstd, C, HW, B, relu, 0, (float *)dx,
                                (float *)dres, dgamma, dbeta, groups);
         else
-            hipLaunchKernelGGL((bn_small_bwd_kernel<bf16n>), dim3(C), dim3(SB), 0, st, (const bf16n *)dy, (const bf16n *)y,
+            MDX_BN_SMALL(bwd, bf16n, (const bf16n *)dy, (const bf16n *)y,
                                (const bf16n *)x, gamma, save_mean, save_invstd, C, HW, B, relu, 0, (bf16n *)dx,
                                (bf16n *)dres, dgamma, dbeta, groups);
         return check_launch();
