@@ -381,7 +381,8 @@ static __device__ __forceinline__ void resample_h_rows(const PackedJob &J, const
         // window starts in the (mirrored, when flipped) source row.  Unflipped: column a starts first (bounds are monotonic);
         // flipped: column b does.  `first` starts at p0, `second` d pixels later
         const int pa = FLIP ? last - xa - (na - 1) : xa, pb = FLIP ? last - xb - (nb - 1) : xb;
-        const int p0 = FLIP ? pb : pa, d = FLIP ? pa - pb : pb - pa;
+        const int p0 = FLIP ? pb : pa, d = min(max(FLIP ? pa - pb : pb - pa, 0), klead);   // (0 <= d <= lead by the table's construction;
+                                                                                           //  clamped: a wrong table must not read outside it)
         const int nf = FLIP ? nb : na, ns = FLIP ? na : nb;
         const int cf = xw0 + (FLIP ? jb : ja), cs = xw0 + (FLIP ? ja : jb);
         lds_v_u8 q = (lds_v_u8)(lds + lane * pitch + (3 * p0 - a0));
