@@ -212,7 +212,9 @@ constexpr int HW_ROWS = 64;
 #define MDX_HW_ROWT 1
 #endif
 constexpr int HW_ROWT = MDX_HW_ROWT;        // 64-row tiles per block, one after the other (A/B builds: -DMDX_HW_ROWT=2 ...)
-constexpr int HW_LDS_BUDGET = 40 * 1024;    // preferred LDS per block (4 blocks = 16 waves per CU)
+constexpr int HW_LDS_BUDGET = 32 * 1024;    // preferred LDS per block (5-6 blocks per CU).  Re-swept on the round-4 kernel (tools/r4_rows_lds.sh,
+                                            // stage time per batch): 24 KB 151 us, 32 KB 132-134 (32 / 16 / 8 / 4 columns per block at the four
+                                            // scales), 40 KB 134-137 (32 / 32 / 16 / 4), 45-56 KB 133-135 (64 / 32 / 16 / 8), 64 KB 153
 constexpr int HW_LDS_MAX = 64 * 1024;       // a 4-column block may take this much; beyond it the job keeps the gather form
 typedef volatile uint8_t __attribute__((address_space(3))) *lds_v_u8;
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
