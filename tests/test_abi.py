@@ -131,3 +131,15 @@ def test_cpu_tensors_are_refused_loudly():
     import model_layer
     with pytest.raises(_lib.MdxError):
         model_layer.disparity2depth(torch.rand(1, 1, 8, 8), 0.1, 100)
+
+
+def test_graft_entry_build():
+    """the driver's "does it build" entry point: compiles what is stale (nothing, after this module's own import), builds the oracle,
+    checks the library's version against the header's -- it asserted a stale MDX_VERSION once"""
+    import re
+    import __graft_entry__ as g
+    g.build()
+    header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "mdx.h")).read()
+    want = int(re.search(r"#define\s+MDX_VERSION\s+(\d+)", header).group(1))
+    from mdx import _lib
+    assert _lib.lib().mdx_version() == want
