@@ -63,6 +63,8 @@ def _pil_resize(img, oh, ow, flip):
     dict(sizes=[(9, 4200), (7, 4100)], out=(8, 2112)),                                     # vertical pass: a row wider than a block (264 threads)
     dict(sizes=[(20, 30), (19, 28)], out=(130, 136)),                                      # upscale large enough for the 8-byte vertical form, 15 rows per block
     dict(sizes=[(40, 100)], out=(30, 36)),                                                 # out_w % 4 == 0, % 8 != 0: dword stores, byte vertical pass
+    dict(sizes=[(40, 300), (37, 290)], out=(129, 136)),                                    # 8-byte vertical form (two rows per thread) with an ODD number of rows: a lone last row
+    dict(sizes=[(300, 40)], out=(67, 256)),                                                # the same, downscaling rows (windows of neighbouring rows 4.5 apart), odd rows
 ])
 def test_resize_lanczos_bit_exact(G, IP, case):
     rng = np.random.default_rng(len(case["sizes"]) * 1000 + case["out"][1])
