@@ -270,3 +270,50 @@ def test_train_kernel_projection_per_scale(G):
     for s in range(3):
         G.assert_close(d1[s].grad, d2[s].grad.cpu().numpy(), "grad disp s%d" % s)
         G.assert_close(P1[s].grad, P2[s].grad.cpu().numpy(), "grad P s%d" % s)
+
+
+@pytest.mark.parametrize("B,H,W,S", [
+    (12, 192, 640, 2),      # BASELINE configs[1]: the bench's batch
+    (12, 192, 640, 3),      # configs[4]: mono + stereo (the LOW form)
+    (8, 320, 1024, 2),      # configs[3]
+])
+def test_step_path_properties_at_baseline_sizes(G, B, H, W, S):
+    """Size-independent properties of the step's own path (prologue -> training kernel <S, grad, PRE> -> finishing pass) at the
+    BASELINE batch sizes, where the oracle would take minutes: (1) two launches on the same inputs agree bit for bit in every
+    output, gradients included (fixed summation orders, no atomics on floats); (2) an image's per-pixel results do not depend on
+    the batch it sits in -- images 0 and B-1 run alone give the bits they got inside the batch (chunk schedule, work-item
+    numbering and XCD grouping all differ between the two launches); (3) every scale's loss sum is the float64 sum of its
+    to_optimise map to 1e-6."""
+    colors, K, invK, Ts, rng = _synth_images(B, H, W, S, seed=97 + S)
+    from oracle import oracle as orc
+    nscales = 4
+    disps_np = [rng.rand(B, 1, H >> s, W >> s).astype(np.float32) for s in range(nscales)]
+    noises_np = [rng.randn(B, S, H, W).astype(np.float32) for _ in range(nscales)]
+    P = np.stack([orc.compose_projection(K, T) for T in Ts])
+
+    def run(sel):
+        srcs = [G.t(x[sel]) for x in colors[1:]]
+        disps = [G.t(x[sel]).requires_grad_(True) for x in disps_np]
+        Pt = G.t(np.ascontiguousarray(P[:, sel])).requires_grad_(True)
+        pre = G.F.photometric_prologue(G.t(colors[0][sel]), srcs, nscales, automask=True, noises=[G.t(x[sel]) for x in noises_np])
+        out = G.F.photometric_train(disps, Pt, G.t(colors[0][sel]), srcs, G.t(invK[sel]), automask=True, need_depth=True,
+                                    need_to_opt=True, pre=pre)
+        out["sums"].sum().backward()
+        return out, [d.grad for d in disps], Pt.grad
+
+    full = slice(0, B)
+    a, ga, gPa = run(full)
+    b, gb, gPb = run(full)
+    for s in range(nscales):
+        assert torch.equal(a["idx"][s], b["idx"][s]) and torch.equal(a["to_opt"][s], b["to_opt"][s]), "determinism s%d" % s
+        assert torch.equal(ga[s], gb[s]), "determinism of the disparity gradient s%d" % s
+        tot = float(a["to_opt"][s].double().sum())
+        assert abs(float(a["sums"][s].detach()) - tot) <= 1e-6 * abs(tot), "loss sum s%d" % s
+    assert torch.equal(a["sums"], b["sums"]) and torch.equal(gPa, gPb) and torch.equal(a["depth"], b["depth"])
+    for n in (0, B - 1):
+        one, g1, _ = run(slice(n, n + 1))
+        assert torch.equal(one["depth"][0], a["depth"][n])
+        for s in range(nscales):
+            assert torch.equal(one["idx"][s][0], a["idx"][s][n]), "image %d alone, idx s%d" % (n, s)
+            assert torch.equal(one["to_opt"][s][0], a["to_opt"][s][n]), "image %d alone, to_optimise s%d" % (n, s)
+            assert torch.equal(g1[s][0], ga[s][n]), "image %d alone, disparity gradient s%d" % (n, s)
