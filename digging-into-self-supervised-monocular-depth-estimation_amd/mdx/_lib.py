@@ -58,6 +58,9 @@ SYMBOLS = {
     "mdx_decoder_glue_fwd": C.c_int, "mdx_decoder_glue_bwd": C.c_int, "mdx_decoder_glue_workspace_bytes": C.c_size_t,
     "mdx_maxpool3s2_fwd": C.c_int, "mdx_maxpool3s2_bwd": C.c_int,
     "mdx_bn_workspace_bytes": C.c_size_t, "mdx_bn_act_fwd": C.c_int, "mdx_bn_act_bwd": C.c_int,
+    "mdx_bn_nhwc_workspace_bytes": C.c_size_t, "mdx_bn_act_nhwc_fwd": C.c_int, "mdx_bn_act_nhwc_bwd": C.c_int,
+    "mdx_decoder_glue_nhwc_fwd": C.c_int, "mdx_decoder_glue_nhwc_bwd": C.c_int,
+    "mdx_decoder_glue_nhwc_workspace_bytes": C.c_size_t, "mdx_maxpool3s2_nhwc_fwd": C.c_int, "mdx_maxpool3s2_nhwc_bwd": C.c_int,
     "mdx_param2matrix_fwd": C.c_int, "mdx_param2matrix_bwd": C.c_int,
     "mdx_train_desc_init": C.c_int, "mdx_photometric_train_workspace_bytes": C.c_size_t,
     "mdx_photometric_train": C.c_int, "mdx_photometric_prologue": C.c_int, "mdx_photometric_train_pre": C.c_int,
@@ -104,15 +107,18 @@ def check(status, what):
         raise MdxError("%s failed: %s (%d)" % (what, lib().mdx_status_string(status).decode(), status))
 
 
-def ptr(t, dtype=torch.float32, optional=False):
-    """Raw device pointer of a contiguous CUDA/HIP tensor."""
+def ptr(t, dtype=torch.float32, optional=False, cl=False):
+    """Raw device pointer of a contiguous CUDA/HIP tensor (cl: of a 4-D tensor whose memory is channels-last, [B][H][W][C])."""
     if t is None:
         if optional:
             return None
         raise MdxError("required tensor is None")
     if not t.is_cuda:
         raise MdxError("mdx kernels run on the GPU only: got a %s tensor (no CPU fallback)" % t.device)
-    if t.dtype != dtype or not t.is_contiguous():
+    if cl:
+        if t.dtype != dtype or t.dim() != 4 or not t.is_contiguous(memory_format=torch.channels_last):
+            raise MdxError("expected a channels-last %s map, got %s %s strides %s" % (dtype, t.dtype, tuple(t.shape), t.stride()))
+    elif t.dtype != dtype or not t.is_contiguous():
         raise MdxError("expected contiguous %s, got %s contiguous=%s" % (dtype, t.dtype, t.is_contiguous()))
     if t.device.index != torch.cuda.current_device():
         # stream() hands the CURRENT device's stream to the library: kernels would run on that device with another

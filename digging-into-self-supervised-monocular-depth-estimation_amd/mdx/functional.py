@@ -599,8 +599,11 @@ def min_automask(ident, noise, reproj, automask=True, need_combined=False):
     return to_opt, idx, comb
 
 
-# ---- network glue around the convolutions (csrc/glue.hip) ---------------------------------------------------------
+# ---- network glue around the convolutions (csrc/glue.hip, csrc/glue_nhwc.hip) -------------------------------------
+# Every op below has a planar (NCHW memory) and a channels-last ([B][H][W][C] memory) form; the layout of the first
+# map decides, the other maps are brought to it, outputs and gradients come back in it.
 _DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1}
+_CL = torch.channels_last
 
 
 def _glue_dtype(t, what):
@@ -611,54 +614,74 @@ def _glue_dtype(t, what):
     return _DTYPE_CODE[t.dtype]
 
 
+def is_channels_last(t):
+    """4-D map whose memory is [B][H][W][C] and NOT also [B][C][H][W] (C == 1 or H == W == 1 maps are both: planar)."""
+    return t.dim() == 4 and not t.is_contiguous() and t.is_contiguous(memory_format=_CL)
+
+
+def _nhwc_ok(dtype, *channels):
+    """csrc/nhwc_common.hpp: a thread owns one 16-byte channel vector."""
+    n = 4 if dtype == torch.float32 else 8
+    return all(c % n == 0 for c in channels)
+
+
+def _as(t, cl):
+    return t.contiguous(memory_format=_CL) if cl else t.contiguous()
+
+
 class _DecoderGlue(torch.autograd.Function):
     @staticmethod
     def forward(ctx, raw, skip, bias, elu, upsample, out_dtype):
-        raw = raw.contiguous()
         in_code = _glue_dtype(raw, "decoder_glue")
         B, C1, h, w = raw.shape
         u = 2 if upsample else 1
         C2 = 0
         if skip is not None:
-            skip = skip.contiguous()
             if skip.dtype != raw.dtype or skip.shape[0] != B or tuple(skip.shape[2:]) != (u * h, u * w):
                 raise _lib.MdxError("decoder_glue: skip %s %s does not match raw %s %s (x%d)"
                                     % (tuple(skip.shape), skip.dtype, tuple(raw.shape), raw.dtype, u))
             C2 = skip.shape[1]
+        cl = is_channels_last(raw) and _nhwc_ok(raw.dtype, C1, C2)
+        raw = _as(raw, cl)
+        skip = _as(skip, cl) if skip is not None else None
         if bias is not None:
             bias = _f32c(bias)
             if bias.shape != (C1,):
                 raise _lib.MdxError("decoder_glue: bias %s for %d channels" % (tuple(bias.shape), C1))
-        out = torch.empty(B, C1 + C2, u * h + 2, u * w + 2, device=raw.device, dtype=out_dtype)
-        check(lib().mdx_decoder_glue_fwd(ptr(raw, raw.dtype), ptr(skip, raw.dtype) if skip is not None else None,
-                                         ptr(bias) if bias is not None else None, ptr(out, out_dtype), B, C1, C2, h, w,
-                                         int(upsample), int(elu), in_code, _DTYPE_CODE[out_dtype], stream()),
-              "mdx_decoder_glue_fwd")
+        out = torch.empty(B, C1 + C2, u * h + 2, u * w + 2, device=raw.device, dtype=out_dtype,
+                          memory_format=_CL if cl else torch.contiguous_format)
+        fn = lib().mdx_decoder_glue_nhwc_fwd if cl else lib().mdx_decoder_glue_fwd
+        check(fn(ptr(raw, raw.dtype, cl=cl), ptr(skip, raw.dtype, cl=cl) if skip is not None else None,
+                 ptr(bias) if bias is not None else None, ptr(out, out_dtype, cl=cl), B, C1, C2, h, w,
+                 int(upsample), int(elu), in_code, _DTYPE_CODE[out_dtype], stream()), "mdx_decoder_glue_fwd")
         ctx.save_for_backward(raw, bias)
-        ctx.meta = (C2, bool(elu), bool(upsample), out_dtype)
+        ctx.meta = (C2, bool(elu), bool(upsample), out_dtype, cl)
         return out
 
     @staticmethod
     def backward(ctx, gout):
         raw, bias = ctx.saved_tensors
-        C2, elu, upsample, out_dtype = ctx.meta
+        C2, elu, upsample, out_dtype, cl = ctx.meta
         B, C1, h, w = raw.shape
         u = 2 if upsample else 1
-        gout = gout.contiguous().to(out_dtype)
+        gout = _as(gout.to(out_dtype), cl)
+        fmt = _CL if cl else torch.contiguous_format
         graw = torch.empty_like(raw)
-        gskip = torch.empty(B, C2, u * h, u * w, device=raw.device, dtype=raw.dtype) if C2 else None
+        gskip = torch.empty(B, C2, u * h, u * w, device=raw.device, dtype=raw.dtype, memory_format=fmt) if C2 else None
         dbias = ws = None
         nws = 0
+        code = _DTYPE_CODE[raw.dtype]
         if bias is not None:
             dbias = torch.empty(C1, device=raw.device, dtype=torch.float32)
-            nws = lib().mdx_decoder_glue_workspace_bytes(B, C1, h, w)
+            nws = (lib().mdx_decoder_glue_nhwc_workspace_bytes(B, C1, h, w, code) if cl
+                   else lib().mdx_decoder_glue_workspace_bytes(B, C1, h, w))
             ws = torch.empty(nws // 4 + 1, device=raw.device, dtype=torch.float32)
-        check(lib().mdx_decoder_glue_bwd(ptr(gout, out_dtype), ptr(raw, raw.dtype),
-                                         ptr(bias) if bias is not None else None, ptr(graw, raw.dtype),
-                                         ptr(gskip, raw.dtype) if C2 else None, ptr(dbias) if bias is not None else None,
-                                         B, C1, C2, h, w, int(upsample), int(elu), _DTYPE_CODE[raw.dtype],
-                                         _DTYPE_CODE[out_dtype], ptr(ws) if ws is not None else None, C.c_size_t(nws),
-                                         stream()), "mdx_decoder_glue_bwd")
+        fn = lib().mdx_decoder_glue_nhwc_bwd if cl else lib().mdx_decoder_glue_bwd
+        check(fn(ptr(gout, out_dtype, cl=cl), ptr(raw, raw.dtype, cl=cl), ptr(bias) if bias is not None else None,
+                 ptr(graw, raw.dtype, cl=cl), ptr(gskip, raw.dtype, cl=cl) if C2 else None,
+                 ptr(dbias) if bias is not None else None, B, C1, C2, h, w, int(upsample), int(elu), code,
+                 _DTYPE_CODE[out_dtype], ptr(ws) if ws is not None else None, C.c_size_t(nws), stream()),
+              "mdx_decoder_glue_bwd")
         return graw, gskip, dbias, None, None, None
 
 
@@ -668,7 +691,8 @@ def decoder_glue(raw, skip=None, elu=True, upsample=True, out_dtype=None, bias=N
     raw [B,C1,h,w] (the convolution output BEFORE its ELU), skip [B,C2,u*h,u*w] or None -> [B,C1+C2,u*h+2,u*w+2].
     bias [C1]: the bias of the convolution that produced raw when that convolution was run without it (its add and
     its gradient reduction then happen inside these kernels instead of in two more passes over the map).
-    elu / upsample switch the two stages off (plain pad: elu=False, upsample=False).  float32 or bfloat16."""
+    elu / upsample switch the two stages off (plain pad: elu=False, upsample=False).  float32 or bfloat16; a
+    channels-last `raw` gives a channels-last result (csrc/glue_nhwc.hip)."""
     out_dtype = out_dtype or raw.dtype
     if skip is not None and skip.dtype != raw.dtype:
         skip = skip.to(raw.dtype)
@@ -677,99 +701,146 @@ def decoder_glue(raw, skip=None, elu=True, upsample=True, out_dtype=None, bias=N
 
 class _MaxPool3s2(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x):
-        x = x.contiguous()
+    def forward(ctx, x, fork):
         code = _glue_dtype(x, "maxpool3s2")
         B, Cc, H, W = x.shape
+        cl = is_channels_last(x) and _nhwc_ok(x.dtype, Cc)
+        x = _as(x, cl)
         Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-        out = torch.empty(B, Cc, Ho, Wo, device=x.device, dtype=x.dtype)
-        arg = torch.empty(B, Cc, Ho, Wo, device=x.device, dtype=torch.uint8)
-        check(lib().mdx_maxpool3s2_fwd(ptr(x, x.dtype), ptr(out, x.dtype), ptr(arg, torch.uint8), B * Cc, H, W, code,
-                                       stream()), "mdx_maxpool3s2_fwd")
+        fmt = _CL if cl else torch.contiguous_format
+        out = torch.empty(B, Cc, Ho, Wo, device=x.device, dtype=x.dtype, memory_format=fmt)
+        arg = torch.empty(B, Cc, Ho, Wo, device=x.device, dtype=torch.uint8, memory_format=fmt)
+        if cl:
+            check(lib().mdx_maxpool3s2_nhwc_fwd(ptr(x, x.dtype, cl=True), ptr(out, x.dtype, cl=True),
+                                                ptr(arg, torch.uint8, cl=True), B, Cc, H, W, code, stream()),
+                  "mdx_maxpool3s2_nhwc_fwd")
+        else:
+            check(lib().mdx_maxpool3s2_fwd(ptr(x, x.dtype), ptr(out, x.dtype), ptr(arg, torch.uint8), B * Cc, H, W, code,
+                                           stream()), "mdx_maxpool3s2_fwd")
         ctx.save_for_backward(arg)
-        ctx.meta = (H, W, x.dtype)
-        return out
+        ctx.meta = (H, W, x.dtype, cl)
+        ctx.set_materialize_grads(False)
+        return (out, out.view_as(out)) if fork else out
 
     @staticmethod
-    def backward(ctx, gout):
+    def backward(ctx, gout, gout2=None):
         (arg,) = ctx.saved_tensors
-        H, W, dtype = ctx.meta
+        H, W, dtype, cl = ctx.meta
         B, Cc = arg.shape[:2]
-        gout = gout.contiguous().to(dtype)
-        gin = torch.empty(B, Cc, H, W, device=gout.device, dtype=dtype)
-        check(lib().mdx_maxpool3s2_bwd(ptr(gout, dtype), ptr(arg, torch.uint8), ptr(gin, dtype), B * Cc, H, W,
-                                       _DTYPE_CODE[dtype], stream()), "mdx_maxpool3s2_bwd")
-        return gin
+        gout, gout2 = _two_grads(gout, gout2, dtype, cl, fused_add=cl)
+        if gout is None:
+            return None, None
+        gin = torch.empty(B, Cc, H, W, device=gout.device, dtype=dtype, memory_format=_CL if cl else torch.contiguous_format)
+        if cl:
+            check(lib().mdx_maxpool3s2_nhwc_bwd(ptr(gout, dtype, cl=True), ptr(gout2, dtype, cl=True) if gout2 is not None else None,
+                                                ptr(arg, torch.uint8, cl=True), ptr(gin, dtype, cl=True), B, Cc, H, W,
+                                                _DTYPE_CODE[dtype], stream()), "mdx_maxpool3s2_nhwc_bwd")
+        else:
+            check(lib().mdx_maxpool3s2_bwd(ptr(gout, dtype), ptr(arg, torch.uint8), ptr(gin, dtype), B * Cc, H, W,
+                                           _DTYPE_CODE[dtype], stream()), "mdx_maxpool3s2_bwd")
+        return gin, None
 
 
-def maxpool3s2(x):
-    """MaxPool2d(kernel_size=3, stride=2, padding=1) (ResNet stem); backward is a gather, not ATen's atomics."""
-    return _MaxPool3s2.apply(x)
+def _two_grads(g1, g2, dtype, cl, fused_add):
+    """The one or two upstream gradients of a forked output, in the op's dtype and layout.  fused_add: the kernel adds
+    the second one on the way in (channels-last forms); otherwise they are added here."""
+    gs = [_as(g.to(dtype), cl) for g in (g1, g2) if g is not None]
+    if not gs:
+        return None, None
+    if len(gs) == 2 and not fused_add:
+        gs = [gs[0] + gs[1]]
+    return gs[0], (gs[1] if len(gs) == 2 else None)
 
 
-# ---- training-mode BatchNorm2d fused with residual add and ReLU (csrc/norm.hip) -----------------------------------
+def maxpool3s2(x, fork=False):
+    """MaxPool2d(kernel_size=3, stride=2, padding=1) (ResNet stem); backward is a gather, not ATen's atomics.
+    fork: return the result twice (two tensors on one storage, not to be modified in place) for its two consumers --
+    the backward then receives their gradients separately and adds them inside its kernel."""
+    return _MaxPool3s2.apply(x, bool(fork))
+
+
+# ---- training-mode BatchNorm2d fused with residual add and ReLU (csrc/norm.hip, csrc/norm_nhwc.hip) ---------------
 class _BnAct(torch.autograd.Function):
     """groups > 1: the batch is `groups` consecutive sub-batches, each normalised with its own statistics and the
     running statistics updated once per sub-batch, in order -- exactly what `groups` separate calls of the module
     would do (the pose network sees both frame pairs of a step in one batch this way)."""
 
     @staticmethod
-    def forward(ctx, x, res, weight, bias, running_mean, running_var, eps, momentum, relu, groups):
-        x = x.contiguous()
+    def forward(ctx, x, res, weight, bias, running_mean, running_var, eps, momentum, relu, groups, fork):
         code = _glue_dtype(x, "bn_act")
         B, Cc, H, W = x.shape
         if B % groups:
             raise _lib.MdxError("bn_act: batch %d is not divisible into %d groups" % (B, groups))
+        cl = is_channels_last(x) and _nhwc_ok(x.dtype, Cc)
+        x = _as(x, cl)
         if res is not None:
-            res = res.contiguous()
             if res.shape != x.shape or res.dtype != x.dtype:
                 raise _lib.MdxError("bn_act: residual %s %s does not match x %s %s"
                                     % (tuple(res.shape), res.dtype, tuple(x.shape), x.dtype))
+            res = _as(res, cl)
         weight, bias = _f32c(weight), _f32c(bias)
         y = torch.empty_like(x)
         save_mean = torch.empty(groups, Cc, device=x.device, dtype=torch.float32)
         save_invstd = torch.empty(groups, Cc, device=x.device, dtype=torch.float32)
         Bg = B // groups
-        nws = lib().mdx_bn_workspace_bytes(Bg, Cc, H, W)
+        nws = lib().mdx_bn_nhwc_workspace_bytes(Bg, Cc, H, W, groups, code) if cl else lib().mdx_bn_workspace_bytes(Bg, Cc, H, W)
         ws = torch.empty(nws // 4 + 1, device=x.device, dtype=torch.float32)
-        check(lib().mdx_bn_act_fwd(
-            ptr(x, x.dtype), ptr(res, x.dtype) if res is not None else None, ptr(weight), ptr(bias),
-            ptr(running_mean) if running_mean is not None else None,
-            ptr(running_var) if running_var is not None else None, ptr(y, x.dtype), ptr(save_mean), ptr(save_invstd),
-            Bg, Cc, H, W, groups, C.c_float(eps), C.c_float(momentum), int(relu), code, ptr(ws), C.c_size_t(nws),
-            stream()), "mdx_bn_act_fwd")
+        fn = lib().mdx_bn_act_nhwc_fwd if cl else lib().mdx_bn_act_fwd
+        check(fn(ptr(x, x.dtype, cl=cl), ptr(res, x.dtype, cl=cl) if res is not None else None, ptr(weight), ptr(bias),
+                 ptr(running_mean) if running_mean is not None else None,
+                 ptr(running_var) if running_var is not None else None, ptr(y, x.dtype, cl=cl), ptr(save_mean),
+                 ptr(save_invstd), Bg, Cc, H, W, groups, C.c_float(eps), C.c_float(momentum), int(relu), code, ptr(ws),
+                 C.c_size_t(nws), stream()), "mdx_bn_act_fwd")
         ctx.save_for_backward(x, y, weight, save_mean, save_invstd)
-        ctx.meta = (bool(relu), res is not None, groups)
+        ctx.meta = (bool(relu), res is not None, groups, cl)
         ctx.mark_non_differentiable(*[t for t in (running_mean, running_var) if t is not None])
-        return y
+        ctx.set_materialize_grads(False)
+        return (y, y.view_as(y)) if fork else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dy2=None):
         x, y, weight, save_mean, save_invstd = ctx.saved_tensors
-        relu, has_res, groups = ctx.meta
+        relu, has_res, groups, cl = ctx.meta
+        none = (None,) * 11
+        dy, dy2 = _two_grads(dy, dy2, x.dtype, cl, fused_add=cl)
+        if dy is None:
+            return none
         B, Cc, H, W = x.shape
         Bg = B // groups
-        dy = dy.contiguous().to(x.dtype)
+        code = _DTYPE_CODE[x.dtype]
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if has_res else None
         dgamma = torch.empty(Cc, device=x.device, dtype=torch.float32)
         dbeta = torch.empty(Cc, device=x.device, dtype=torch.float32)
-        nws = lib().mdx_bn_workspace_bytes(Bg, Cc, H, W)
-        ws = torch.empty(nws // 4 + 1, device=x.device, dtype=torch.float32)
-        check(lib().mdx_bn_act_bwd(
-            ptr(dy, x.dtype), ptr(y, x.dtype), ptr(x, x.dtype), ptr(weight), ptr(save_mean), ptr(save_invstd),
-            ptr(dx, x.dtype), ptr(dres, x.dtype) if has_res else None, ptr(dgamma), ptr(dbeta), Bg, Cc, H, W, groups,
-            int(relu), _DTYPE_CODE[x.dtype], ptr(ws), C.c_size_t(nws), stream()), "mdx_bn_act_bwd")
-        return dx, dres, dgamma, dbeta, None, None, None, None, None, None
+        if cl:
+            nws = lib().mdx_bn_nhwc_workspace_bytes(Bg, Cc, H, W, groups, code)
+            ws = torch.empty(nws // 4 + 1, device=x.device, dtype=torch.float32)
+            check(lib().mdx_bn_act_nhwc_bwd(
+                ptr(dy, x.dtype, cl=True), ptr(dy2, x.dtype, cl=True) if dy2 is not None else None, ptr(y, x.dtype, cl=True),
+                ptr(x, x.dtype, cl=True), ptr(weight), ptr(save_mean), ptr(save_invstd), ptr(dx, x.dtype, cl=True),
+                ptr(dres, x.dtype, cl=True) if has_res else None, ptr(dgamma), ptr(dbeta), Bg, Cc, H, W, groups, int(relu),
+                code, ptr(ws), C.c_size_t(nws), stream()), "mdx_bn_act_nhwc_bwd")
+        else:
+            nws = lib().mdx_bn_workspace_bytes(Bg, Cc, H, W)
+            ws = torch.empty(nws // 4 + 1, device=x.device, dtype=torch.float32)
+            check(lib().mdx_bn_act_bwd(
+                ptr(dy, x.dtype), ptr(y, x.dtype), ptr(x, x.dtype), ptr(weight), ptr(save_mean), ptr(save_invstd),
+                ptr(dx, x.dtype), ptr(dres, x.dtype) if has_res else None, ptr(dgamma), ptr(dbeta), Bg, Cc, H, W, groups,
+                int(relu), code, ptr(ws), C.c_size_t(nws), stream()), "mdx_bn_act_bwd")
+        return (dx, dres, dgamma, dbeta) + (None,) * 7
 
 
-def bn_act(x, weight, bias, running_mean, running_var, eps=1e-5, momentum=0.1, residual=None, relu=True, groups=1):
+def bn_act(x, weight, bias, running_mean, running_var, eps=1e-5, momentum=0.1, residual=None, relu=True, groups=1,
+           fork=False):
     """Training-mode batch norm over (B,H,W) of x [B,C,H,W] with batch statistics, then `+ residual`, then ReLU
-    (csrc/norm.hip).  Updates running_mean / running_var in place like
+    (csrc/norm.hip; csrc/norm_nhwc.hip when x is channels-last).  Updates running_mean / running_var in place like
     torch.nn.functional.batch_norm(training=True).  float32 or bfloat16 activations, float32 parameters.
-    groups: number of consecutive sub-batches normalised independently (see _BnAct)."""
+    groups: number of consecutive sub-batches normalised independently (see _BnAct).
+    fork: return the result twice (two tensors on one storage, not to be modified in place), one per consumer -- a ResNet
+    block's output feeds the next block's first convolution and its identity path; the backward then receives the two
+    gradients separately and adds them inside its kernel instead of autograd doing so in a pass of its own."""
     return _BnAct.apply(x, residual, weight, bias, running_mean, running_var, float(eps), float(momentum), bool(relu),
-                        int(groups))
+                        int(groups), bool(fork))
 
 
 # ---- param2matrix (csrc/pose.hip) ----------------------------------------------------------------------------------

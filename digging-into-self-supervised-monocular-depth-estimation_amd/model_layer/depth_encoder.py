@@ -67,9 +67,10 @@ class BatchNorm2d(nn.BatchNorm2d):
         return TF.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, self.training,
                              self.momentum, self.eps)
 
-    def act(self, x, residual=None, relu=True):
-        """relu(self(x) + residual) -- on the GPU in training mode as the fused two-pass kernel pair of
-        csrc/norm.hip (statistics pass + normalise/add/ReLU pass; backward likewise), else as the torch ops."""
+    def act(self, x, residual=None, relu=True, fork=False):
+        """relu(self(x) + residual) -- on the GPU in training mode as the fused kernels of csrc/norm.hip (planar maps) /
+        csrc/norm_nhwc.hip (channels-last maps): statistics pass + normalise/add/ReLU pass, backward likewise; else as the
+        torch ops.  fork: the result twice (mdx.functional.bn_act), one tensor per consumer."""
         # csrc/norm.hip: one launch each way for maps up to 24 K elements per channel (kept in registers between the
         # reduction and the apply step), two (statistics pass, apply pass) above -- tools/normbench.py
         fused = (self.training and x.is_cuda and self.track_running_stats and self.momentum is not None
@@ -82,13 +83,14 @@ class BatchNorm2d(nn.BatchNorm2d):
             out = self(x)
             if residual is not None:
                 out = out + residual
-            return TF.relu(out) if relu else out
+            out = TF.relu(out) if relu else out
+            return (out, out) if fork else out
         from mdx import functional as F
         self._pending_batches += self._batch_groups
         if residual is not None and residual.dtype != x.dtype:
             residual = residual.to(x.dtype)
         return F.bn_act(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps, self.momentum,
-                        residual=residual, relu=relu, groups=self._batch_groups)
+                        residual=residual, relu=relu, groups=self._batch_groups, fork=fork)
 
     def _flush_counter(self):
         if self._pending_batches and self.num_batches_tracked is not None:
@@ -103,8 +105,15 @@ class BatchNorm2d(nn.BatchNorm2d):
         self._pending_batches = 0
         super()._load_from_state_dict(*args, **kwargs)
 
+def _pair(x):
+    """A block's input: (for the first convolution, for the identity path) -- two tensors on one storage when the
+    producer forked its output (BatchNorm2d.act(fork=True)), else the same tensor twice."""
+    return x if isinstance(x, tuple) else (x, x)
+
+
 class BasicBlock(nn.Module):
     expansion = 1
+    fork_output = True      # hand the output on as a pair: the producer's backward then adds its two gradients itself
 
     def __init__(self, inplanes, planes, stride=1, downsample=None):
         super().__init__()
@@ -116,13 +125,15 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        identity = x if self.downsample is None else self.downsample[1].act(self.downsample[0](x), relu=False)
+        x, xid = _pair(x)
+        identity = xid if self.downsample is None else self.downsample[1].act(self.downsample[0](xid), relu=False)
         out = self.bn1.act(self.conv1(x))
-        return self.bn2.act(self.conv2(out), residual=identity)
+        return self.bn2.act(self.conv2(out), residual=identity, fork=self.fork_output)
 
 
 class Bottleneck(nn.Module):
     expansion = 4
+    fork_output = True
 
     def __init__(self, inplanes, planes, stride=1, downsample=None):
         super().__init__()
@@ -136,10 +147,11 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        identity = x if self.downsample is None else self.downsample[1].act(self.downsample[0](x), relu=False)
+        x, xid = _pair(x)
+        identity = xid if self.downsample is None else self.downsample[1].act(self.downsample[0](xid), relu=False)
         out = self.bn1.act(self.conv1(x))
         out = self.bn2.act(self.conv2(out))
-        return self.bn3.act(self.conv3(out), residual=identity)
+        return self.bn3.act(self.conv3(out), residual=identity, fork=self.fork_output)
 
 
 _CFG = {18: (BasicBlock, [2, 2, 2, 2]), 34: (BasicBlock, [3, 4, 6, 3]), 50: (Bottleneck, [3, 4, 6, 3]),
@@ -225,16 +237,17 @@ class ResnetEncoder(nn.Module):
     def forward(self, input_image):
         self.features = []
         x = (input_image - 0.45) / 0.225
-        self.features.append(self.encoder.bn1.act(self.encoder.conv1(x)))
-        stem = self.features[-1]
+        # every map below has two consumers (the next layer's first convolution + its identity path, or the decoder's
+        # skip connection + the next layer): producers hand their output on as a pair, see BatchNorm2d.act(fork=True)
+        stem, stem_b = _pair(self.encoder.bn1.act(self.encoder.conv1(x), fork=BasicBlock.fork_output))
+        self.features.append(stem)
         if (stem.is_cuda and stem.dtype in (torch.float32, torch.bfloat16)
                 and stem.shape[0] * stem.shape[1] <= 65535):         # csrc/glue.hip: B*C on a 16-bit grid axis
             from mdx import functional as F      # gather-based backward instead of ATen's atomics (csrc/glue.hip)
-            pooled = F.maxpool3s2(stem)
+            x = F.maxpool3s2(stem_b, fork=BasicBlock.fork_output)
         else:
-            pooled = self.encoder.maxpool(stem)
-        self.features.append(self.encoder.layer1(pooled))
-        self.features.append(self.encoder.layer2(self.features[-1]))
-        self.features.append(self.encoder.layer3(self.features[-1]))
-        self.features.append(self.encoder.layer4(self.features[-1]))
+            x = self.encoder.maxpool(stem_b)
+        for layer in (self.encoder.layer1, self.encoder.layer2, self.encoder.layer3, self.encoder.layer4):
+            x = _pair(layer(x))
+            self.features.append(x[0])
         return self.features

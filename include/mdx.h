@@ -321,6 +321,41 @@ int mdx_bn_act_bwd(const void *dy, const void *y, const void *x, const float *ga
                    const float *save_invstd, void *dx, void *dres, float *dgamma, float *dbeta, int B, int C, int H,
                    int W, int groups, int relu, int dtype, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- the same network glue for CHANNELS-LAST maps (memory [B][H][W][C]; csrc/norm_nhwc.hip, csrc/glue_nhwc.hip) ----
+ * What MIOpen's implicit-GEMM convolutions read and write without a layout transpose on either side.  Same operators,
+ * same arithmetic and summation order per element as the planar entry points above; a thread owns one 16-byte channel
+ * vector, so every channel count must be a multiple of 4 (float32) / 8 (bfloat16) and every map pointer 16-byte aligned
+ * (else MDX_ERR_BAD_SHAPE / MDX_ERR_MISALIGNED: the caller then takes the planar entry points).
+ *
+ * mdx_bn_act_nhwc_*: model_layer/depth_encoder.py:27,95 (BatchNorm2d + ReLU + residual of every ResNet block).
+ * x, res, y, dy, dx, dres [groups*B][H][W][C]; three launches each way (block partials, a float64 finalize pass, apply),
+ * no atomics.  dy2 (may be NULL): a second upstream gradient of y, added on the way in -- a block's output feeds the next
+ * block's first convolution AND its identity path, and autograd would otherwise spend one more pass over the map on
+ * adding the two. */
+size_t mdx_bn_nhwc_workspace_bytes(int B, int C, int H, int W, int groups, int dtype);
+int mdx_bn_act_nhwc_fwd(const void *x, const void *res, const float *gamma, const float *beta, float *run_mean,
+                        float *run_var, void *y, float *save_mean, float *save_invstd, int B, int C, int H, int W,
+                        int groups, float eps, float momentum, int relu, int dtype, void *workspace,
+                        size_t workspace_bytes, void *stream);
+int mdx_bn_act_nhwc_bwd(const void *dy, const void *dy2, const void *y, const void *x, const float *gamma,
+                        const float *save_mean, const float *save_invstd, void *dx, void *dres, float *dgamma,
+                        float *dbeta, int B, int C, int H, int W, int groups, int relu, int dtype, void *workspace,
+                        size_t workspace_bytes, void *stream);
+/* mdx_decoder_glue_nhwc_*: model_layer/depth_decoder.py:44-47,96-106.  raw [B][h][w][C1], skip [B][u*h][u*w][C2],
+ * out / gout [B][u*h+2][u*w+2][C1+C2]; dtype pairs as mdx_decoder_glue_fwd. */
+int mdx_decoder_glue_nhwc_fwd(const void *raw, const void *skip, const float *bias, void *out, int B, int C1, int C2,
+                              int h, int w, int upsample, int elu, int in_dtype, int out_dtype, void *stream);
+size_t mdx_decoder_glue_nhwc_workspace_bytes(int B, int C1, int h, int w, int in_dtype);
+int mdx_decoder_glue_nhwc_bwd(const void *gout, const void *raw, const float *bias, void *graw, void *gskip,
+                              float *dbias, int B, int C1, int C2, int h, int w, int upsample, int elu, int in_dtype,
+                              int out_dtype, void *workspace, size_t workspace_bytes, void *stream);
+/* mdx_maxpool3s2_nhwc_*: the ResNet stem's MaxPool2d(3, 2, 1).  in / gin [B][H][W][C]; out, arg, gout [B][Ho][Wo][C];
+ * gout2 (may be NULL): a second upstream gradient, added on the way in. */
+int mdx_maxpool3s2_nhwc_fwd(const void *in, void *out, uint8_t *arg, int B, int C, int H, int W, int dtype,
+                            void *stream);
+int mdx_maxpool3s2_nhwc_bwd(const void *gout, const void *gout2, const uint8_t *arg, void *gin, int B, int C, int H,
+                            int W, int dtype, void *stream);
+
 /* Train-time depth monitor   replaces model_loss/model_metric.py:70-105 (called every step, model_train.py:69).
  * pred [B,1,h,w] (outputs[("depth",0,0)]), gt [B,1,gh,gw] (0 = no return); window rows r0:r1, cols c0:c1 (the Garg crop).
  * out [8] = abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3, number of valid pixels.  Bilinear resize to the ground truth's

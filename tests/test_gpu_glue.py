@@ -16,18 +16,41 @@ def F():
     from mdx import functional
     return functional
 
+def _leaf(t, dtype, cl):
+    """A leaf on the GPU in the wanted memory layout (cl: channels-last, what csrc/*_nhwc.hip take)."""
+    t = t.to("cuda", dtype)
+    if cl:
+        t = t.contiguous(memory_format=torch.channels_last)
+    return t.requires_grad_(True)
+
+
+def _layout_is(t, cl):
+    return t.is_contiguous(memory_format=torch.channels_last) if cl else t.is_contiguous()
+
+
+GLUE_CASES = [(2, 5, 3, 6, 10, True, True, False), (1, 4, 0, 7, 9, True, False, False), (2, 3, 0, 2, 2, False, False, False),
+              (1, 16, 0, 48, 160, True, True, False), (3, 2, 4, 1, 1, True, True, False),
+              # channels-last maps: channel counts in 16-byte vectors, odd sizes, one- and two-pixel maps, the fold ring
+              (2, 8, 16, 6, 10, True, True, True), (1, 16, 0, 7, 9, True, False, True), (2, 8, 0, 2, 2, False, False, True),
+              (1, 16, 0, 48, 160, True, True, True), (3, 8, 8, 1, 1, True, True, True), (2, 32, 64, 5, 3, True, True, True),
+              (2, 96, 0, 3, 4, False, False, True), (1, 512, 0, 2, 3, False, False, True), (2, 256, 256, 2, 2, True, True, True)]
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("cfg", [(2, 5, 3, 6, 10, True, True), (1, 4, 0, 7, 9, True, False), (2, 3, 0, 2, 2, False, False),
-                                  (1, 16, 0, 48, 160, True, True), (3, 2, 4, 1, 1, True, True)])
+@pytest.mark.parametrize("cfg", GLUE_CASES)
 def test_decoder_glue_matches_torch_ops(F, cfg, dtype):
-    """decoder_glue == ReflectionPad2d(1)(cat(interpolate(ELU(raw), x2 nearest), skip)), forward and backward."""
-    B, C1, C2, h, w, elu, up = cfg
+    """decoder_glue == ReflectionPad2d(1)(cat(interpolate(ELU(raw), x2 nearest), skip)), forward and backward -- planar
+    maps (csrc/glue.hip) and channels-last maps (csrc/glue_nhwc.hip)."""
+    B, C1, C2, h, w, elu, up, cl = cfg
     g = torch.Generator().manual_seed(11)
-    raw = torch.randn(B, C1, h, w, generator=g).to("cuda", dtype).requires_grad_(True)
+    raw = _leaf(torch.randn(B, C1, h, w, generator=g), dtype, cl)
     u = 2 if up else 1
-    skip = torch.randn(B, C2, u * h, u * w, generator=g).to("cuda", dtype).requires_grad_(True) if C2 else None
+    skip = _leaf(torch.randn(B, C2, u * h, u * w, generator=g), dtype, cl) if C2 else None
     bias = torch.randn(C1, generator=g).cuda().requires_grad_(True) if elu else None    # conv bias folded in
     out = F.decoder_glue(raw, skip, elu=elu, upsample=up, bias=bias)
+    if cl:
+        assert F.is_channels_last(raw) or min(C1, h * w) == 1
+        assert _layout_is(out, True), "a channels-last input gives a channels-last result"
     raw2 = raw.detach().clone().requires_grad_(True)
     skip2 = skip.detach().clone().requires_grad_(True) if C2 else None
     bias2 = bias.detach().clone().requires_grad_(True) if bias is not None else None
@@ -46,6 +69,7 @@ def test_decoder_glue_matches_torch_ops(F, cfg, dtype):
     ref.backward(gout)
     gtol = 1e-5 if dtype == torch.float32 else 6e-2   # bf16: the reference rounds after every op, the kernel once
     torch.testing.assert_close(raw.grad.float(), raw2.grad.float(), rtol=gtol, atol=gtol)
+    assert _layout_is(raw.grad, cl)
     if C2:
         torch.testing.assert_close(skip.grad.float(), skip2.grad.float(), rtol=gtol, atol=gtol)
     if bias is not None:
@@ -53,21 +77,31 @@ def test_decoder_glue_matches_torch_ops(F, cfg, dtype):
         assert float((bias.grad - bias2.grad).abs().max()) <= (1e-4 if dtype == torch.float32 else 3e-2) * scale
 
 
-def test_decoder_glue_bf16_to_f32_head_input(F):
-    raw = torch.randn(2, 4, 6, 8).to("cuda", torch.bfloat16)
+@pytest.mark.parametrize("cl", [False, True])
+def test_decoder_glue_bf16_to_f32_head_input(F, cl):
+    raw = _leaf(torch.randn(2, 16, 6, 9), torch.bfloat16, cl)
     out = F.decoder_glue(raw, None, elu=True, upsample=False, out_dtype=torch.float32)
-    ref = torch.nn.ReflectionPad2d(1)(torch.nn.functional.elu(raw.float()))
-    assert out.dtype == torch.float32
+    ref = torch.nn.ReflectionPad2d(1)(torch.nn.functional.elu(raw.detach().float()))
+    assert out.dtype == torch.float32 and _layout_is(out, cl)
     torch.testing.assert_close(out, ref, rtol=1e-6, atol=1e-6)
+    gout = torch.randn(ref.shape, device="cuda")
+    out.backward(gout)
+    raw2 = raw.detach().float().requires_grad_(True)
+    torch.nn.ReflectionPad2d(1)(torch.nn.functional.elu(raw2)).backward(gout)
+    torch.testing.assert_close(raw.grad.float(), raw2.grad, rtol=2e-2, atol=2e-2)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("shape", [(2, 3, 8, 10), (1, 2, 7, 9), (2, 64, 96, 320), (1, 1, 1, 1), (1, 2, 2, 3)])
-def test_maxpool3s2_matches_torch(F, shape, dtype):
+@pytest.mark.parametrize("cl", [False, True])
+@pytest.mark.parametrize("shape", [(2, 3, 8, 10), (1, 2, 7, 9), (2, 64, 96, 320), (1, 1, 1, 1), (1, 2, 2, 3), (2, 8, 7, 9), (1, 16, 2, 3),
+                                   (2, 24, 5, 4), (1, 8, 1, 1)])
+def test_maxpool3s2_matches_torch(F, shape, dtype, cl):
+    """planar (csrc/glue.hip) and channels-last (csrc/glue_nhwc.hip; channel counts of 16-byte vectors -- other shapes fall
+    back to the planar kernels whatever the layout) forms against ATen, ties and odd sizes included."""
     g = torch.Generator().manual_seed(5)
     x = torch.randn(shape, generator=g)
     x[..., ::3] = x[..., :1].clone()                      # ties: the first maximum of the window must win, as in ATen
-    x = x.to("cuda", dtype).requires_grad_(True)
+    x = _leaf(x, dtype, cl)
     y = F.maxpool3s2(x)
     x2 = x.detach().clone().requires_grad_(True)
     ref = torch.nn.functional.max_pool2d(x2, 3, 2, 1)
@@ -80,13 +114,54 @@ def test_maxpool3s2_matches_torch(F, shape, dtype):
     torch.testing.assert_close(x.grad.float(), x2.grad.float(), rtol=tol, atol=tol)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cl", [False, True])
+def test_forked_outputs_sum_their_gradients(F, dtype, cl):
+    """maxpool3s2(fork=True) / bn_act(fork=True) return the result twice; the backward receives the two upstream gradients
+    separately and adds them (inside the kernel for channels-last maps) == autograd's sum over the two consumers."""
+    g = torch.Generator().manual_seed(9)
+    x0 = torch.randn(2, 16, 9, 11, generator=g)
+    w0, b0 = torch.rand(16, generator=g) + 0.5, torch.randn(16, generator=g)
+    for op in ("pool", "bn"):
+        res = {}
+        for fork in (True, False):
+            x = _leaf(x0, dtype, cl)
+            w, b = w0.cuda().requires_grad_(True), b0.cuda().requires_grad_(True)
+            rm, rv = torch.zeros(16, device="cuda"), torch.ones(16, device="cuda")
+            if op == "pool":
+                out = F.maxpool3s2(x, fork=fork)
+            else:
+                out = F.bn_act(x, w, b, rm, rv, 1e-5, 0.1, relu=True, fork=fork)
+            ya, yb = out if fork else (out, out)
+            if fork:
+                assert ya.data_ptr() == yb.data_ptr() and torch.equal(ya, yb)
+            ga, gb = torch.randn(ya.shape, generator=g).to("cuda", dtype), torch.randn(ya.shape, generator=g).to("cuda", dtype)
+            g.manual_seed(10)
+            ((ya.float() * ga.float()).sum() + (yb.float() * gb.float()).sum()).backward()
+            res[fork] = (x.grad.float(), w.grad, b.grad)
+            # only the second output used: the first gradient is None
+            x1 = _leaf(x0, dtype, cl)
+            out1 = F.maxpool3s2(x1, fork=True) if op == "pool" else F.bn_act(x1, w0.cuda(), b0.cuda(), None, None, 1e-5, 0.1, fork=True)
+            out1[1].float().square().sum().backward()
+            assert torch.isfinite(x1.grad).all()
+        tol = 1e-5 if dtype == torch.float32 else 3e-2
+        torch.testing.assert_close(res[True][0], res[False][0], rtol=tol, atol=tol, msg=op)
+        if op == "bn":
+            torch.testing.assert_close(res[True][1], res[False][1], rtol=10 * tol, atol=10 * tol)
+            torch.testing.assert_close(res[True][2], res[False][2], rtol=10 * tol, atol=10 * tol)
+
+
+@pytest.mark.parametrize("cl", [False, True])
 @pytest.mark.parametrize("amp", [False, True])
-def test_decoder_glue_path_equals_module_path(amp):
-    """DepthDecoder on the GPU (glue path) == the same module run op by op (the CPU code path, forced)."""
+def test_decoder_glue_path_equals_module_path(amp, cl):
+    """DepthDecoder on the GPU (glue path) == the same module run op by op (the CPU code path, forced); cl: the whole
+    network in channels-last memory (csrc/glue_nhwc.hip between the convolutions)."""
     from model_layer import ResnetEncoder, DepthDecoder
     torch.manual_seed(3)
     enc = ResnetEncoder(18, False).cuda()
     dec = DepthDecoder(enc.num_ch_enc).cuda()
+    if cl:
+        enc, dec = enc.to(memory_format=torch.channels_last), dec.to(memory_format=torch.channels_last)
     img = torch.rand(2, 3, 64, 96, device="cuda")
     with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
         feats = [f.detach().requires_grad_(True) for f in enc(img)]
@@ -114,9 +189,12 @@ def test_decoder_glue_path_equals_module_path(amp):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cl", [False, True])
 @pytest.mark.parametrize("cfg", [(12, 64, 48, 160, True, True), (3, 7, 5, 9, False, True), (2, 16, 96, 320, False, True),
-                                 (4, 32, 6, 20, True, False), (2, 8, 3, 3, False, False), (1, 5, 130, 67, True, True)])
-def test_bn_act_matches_torch(F, cfg, dtype):
+                                 (4, 32, 6, 20, True, False), (2, 8, 3, 3, False, False), (1, 5, 130, 67, True, True),
+                                 (1, 8, 130, 67, True, True), (3, 24, 5, 9, True, True), (2, 512, 3, 5, False, True),
+                                 (1, 2048, 2, 3, True, True), (5, 40, 1, 1, False, False)])
+def test_bn_act_matches_torch(F, cfg, dtype, cl):
     """bn_act == relu(batch_norm(x, training=True) + residual): output, running statistics, all four gradients,
     against torch's CPU batch norm in float64 (MIOpen's GPU batch norm drops elements for H*W % 4 != 0 planes --
     db off by O(1) on the (130, 67) case below -- so it cannot be the oracle here)."""
@@ -129,7 +207,10 @@ def test_bn_act_matches_torch(F, cfg, dtype):
     gy0 = torch.randn(B, Cc, H, W, generator=g).to(dtype)
 
     def leaf(t, dev, dt):
-        return t.to(dev, dt).requires_grad_(True)
+        t = t.to(dev, dt)
+        if cl and dev == "cuda" and t.dim() == 4:
+            t = t.contiguous(memory_format=torch.channels_last)
+        return t.requires_grad_(True)
     # float64 reference on the CPU (from the same, already rounded, inputs)
     x2, w2, b2 = leaf(x0, "cpu", torch.float64), leaf(w0, "cpu", torch.float64), leaf(b0, "cpu", torch.float64)
     res2 = leaf(res0, "cpu", torch.float64) if has_res else None
@@ -148,8 +229,9 @@ def test_bn_act_matches_torch(F, cfg, dtype):
     res = leaf(res0, "cuda", dtype) if has_res else None
     rm, rv = rm0.cuda(), rv0.cuda()
     y = F.bn_act(x, w, b, rm, rv, 1e-5, 0.1, residual=res, relu=relu)
-    assert y.dtype == dtype and y.shape == ref.shape
+    assert y.dtype == dtype and y.shape == ref.shape and _layout_is(y, cl)
     y.backward(gy0.cuda())
+    assert _layout_is(x.grad, cl)
 
     def close(a, bb, name, tol):
         scale = float(bb.abs().max()) + 1e-12
@@ -165,8 +247,9 @@ def test_bn_act_matches_torch(F, cfg, dtype):
         close(res.grad, res2.grad, "dres", 1e-5 if f32 else 1e-2)
 
 
+@pytest.mark.parametrize("cl", [False, True])
 @pytest.mark.parametrize("layers", [18, 50])
-def test_encoder_fused_norm_path_equals_module_path(layers, monkeypatch):
+def test_encoder_fused_norm_path_equals_module_path(layers, cl, monkeypatch):
     """ResnetEncoder in training mode on the GPU (fused norm + max-pool kernels) == the same modules op by op."""
     from model_layer import ResnetEncoder
     from model_layer.depth_encoder import BatchNorm2d
@@ -175,15 +258,19 @@ def test_encoder_fused_norm_path_equals_module_path(layers, monkeypatch):
     enc = ResnetEncoder(layers, False).cuda().train()
     ref = ResnetEncoder(layers, False).cuda().train()
     ref.load_state_dict(enc.state_dict())
+    if cl:
+        enc = enc.to(memory_format=torch.channels_last)
     # 128x256: every map's H*W is a multiple of 4 (MIOpen's batch norm, the reference here, is off for other planes)
     img = torch.rand(4, 3, 128, 256, device="cuda")
     feats = enc(img)
+    if cl:
+        assert all(f.is_contiguous(memory_format=torch.channels_last) for f in feats)
     loss = sum(f.mean() for f in feats)
     loss.backward()
     plain = BatchNorm2d.act
     try:
-        BatchNorm2d.act = lambda self, x, residual=None, relu=True: \
-            (lambda o: torch.relu(o) if relu else o)(self(x) if residual is None else self(x) + residual)
+        BatchNorm2d.act = lambda self, x, residual=None, relu=True, fork=False: \
+            (lambda o: (o, o) if fork else o)((lambda o: torch.relu(o) if relu else o)(self(x) if residual is None else self(x) + residual))
         feats2 = ref(img)
         sum(f.mean() for f in feats2).backward()
     finally:
@@ -237,19 +324,21 @@ def test_batched_pose_pairs_equal_the_loop_on_gpu():
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cl", [False, True])
 @pytest.mark.parametrize("shape", [(6, 8, 12, 40), (4, 16, 96, 320)])      # single-launch path, two-pass path
-def test_bn_act_groups_equal_separate_calls(F, shape, dtype):
+def test_bn_act_groups_equal_separate_calls(F, shape, dtype, cl):
     """bn_act(groups=2) on a batch == bn_act on its two halves one after the other (outputs, running statistics,
     gradients): what lets both frame pairs go through the pose network in one batch."""
     B, Cc, H, W = shape
     g = torch.Generator().manual_seed(3)
-    x0 = torch.randn(B, Cc, H, W, generator=g).to("cuda", dtype)
-    r0 = torch.randn(B, Cc, H, W, generator=g).to("cuda", dtype)
+    fmt = torch.channels_last if cl else torch.contiguous_format
+    x0 = torch.randn(B, Cc, H, W, generator=g).to("cuda", dtype).contiguous(memory_format=fmt)
+    r0 = torch.randn(B, Cc, H, W, generator=g).to("cuda", dtype).contiguous(memory_format=fmt)
     w0, b0 = (torch.rand(Cc, generator=g) + 0.5).cuda(), torch.randn(Cc, generator=g).cuda()
     gy = torch.randn(B, Cc, H, W, generator=g).to("cuda", dtype)
     out = {}
     for mode in ("grouped", "separate"):
-        x, r = x0.clone().requires_grad_(True), r0.clone().requires_grad_(True)
+        x, r = x0.clone(memory_format=torch.preserve_format).requires_grad_(True), r0.clone(memory_format=torch.preserve_format).requires_grad_(True)
         w, b = w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
         rm, rv = torch.zeros(Cc, device="cuda"), torch.ones(Cc, device="cuda")
         if mode == "grouped":
