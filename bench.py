@@ -47,7 +47,7 @@ def make_opt(batch, height=192, width=640, frame_ids=(0, -1, 1), num_layers=18, 
     o.num_layers, o.weight_init = num_layers, False          # random init: no checkpoints offline
     o.learning_rate, o.scheduler_step, o.epoch, o.save = 1e-4, 15, 1, "bench"
     o.num_workers, o.synthetic_length = workers, 2 * batch
-    o.fused, o.noise, o.amp, o.channels_last = True, "device", amp, False
+    o.fused, o.noise, o.amp, o.channels_last = True, "device", amp, "auto"
     o.fused_train = True
     return o
 
@@ -396,7 +396,9 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--num-layers", type=int, default=18)
     ap.add_argument("--frame-ids", type=str, default="0 -1 1", help='e.g. "0 -1 1 s" for mono+stereo (configs[4])')
-    ap.add_argument("--channels-last", action="store_true", help="NHWC activations/weights for the conv nets")
+    ap.add_argument("--channels-last", type=str, nargs="?", const="all", default="auto",
+                    help='stages of the networks with channels-last (NHWC) maps: "none", "all", "auto" (the default plan) or a list of '
+                         'stem,layer1..layer4,decoder,pose (mdx/layout.py)')
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark (MIOpen find mode)")
     ap.add_argument("--no-miopen-db", action="store_true", help="ignore the shipped gfx950 find-db (MIOpen heuristics)")
     ap.add_argument("--graph", action="store_true",

@@ -177,19 +177,33 @@ __global__ __launch_bounds__(NB) void decoder_glue_nhwc_bwd_raw_kernel(const TO 
     }
 }
 
-// column sums of part [n][C] -> out [C]: a block = 16 channels x 16 sub-sums, fixed order
-__global__ __launch_bounds__(256) void colsum_finish_kernel(const float *__restrict__ part, int n, int C, float *__restrict__ out)
+// column sums of part [n][C] -> out [C]: a block = 16 channels x 64 sub-sums (1024 threads), eight independent loads per
+// thread and round (the partials come from blocks on all eight XCDs: a loop of single loads is a chain of fabric round trips),
+// fixed order: sub-sums in float32, combined per wave by shuffles and across the 16 waves through LDS
+constexpr int CS_C = 16, CS_S = 64, CS_U = 8;
+__global__ __launch_bounds__(CS_C *CS_S) void colsum_finish_kernel(const float *__restrict__ part, int n, int C, float *__restrict__ out)
 {
-    __shared__ float lds[16][16];
-    const int cl = threadIdx.x % 16, sl = threadIdx.x / 16, c = blockIdx.x * 16 + cl;
+    __shared__ float lds[CS_S / 4][CS_C];
+    const int cl = threadIdx.x % CS_C, sl = threadIdx.x / CS_C, c = blockIdx.x * CS_C + cl;
     float s = 0.f;
-    if (c < C)
-        for (int i = sl; i < n; i += 16) s += part[(size_t)i * C + c];
-    lds[sl][cl] = s;
+    for (int i0 = sl; i0 < n; i0 += CS_S * CS_U) {
+        float v[CS_U];
+#pragma unroll
+        for (int u = 0; u < CS_U; ++u) {
+            const int i = i0 + u * CS_S;
+            v[u] = (c < C && i < n) ? part[(size_t)i * C + c] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < CS_U; ++u) s += v[u];
+    }
+    s += __shfl_down(s, 32, 64);
+    s += __shfl_down(s, 16, 64);
+    if ((threadIdx.x & 63) < CS_C) lds[threadIdx.x >> 6][cl] = s;
     __syncthreads();
-    if (sl == 0 && c < C) {
+    if (threadIdx.x < CS_C && c < C) {
         float tot = 0.f;
-        for (int k = 0; k < 16; ++k) tot += lds[k][cl];
+#pragma unroll
+        for (int k = 0; k < CS_S / 4; ++k) tot += lds[k][cl];
         out[c] = tot;
     }
 }
@@ -412,7 +426,7 @@ MDX_EXPORT int mdx_decoder_glue_nhwc_bwd(const void *gout, const void *raw, cons
     else return MDX_ERR_BAD_SHAPE;
 #undef MDX_GLUE_BWD
     if (dbias)
-        hipLaunchKernelGGL(colsum_finish_kernel, dim3(ceil_div(C1, 16)), dim3(256), 0, st, bias_part,
+        hipLaunchKernelGGL(colsum_finish_kernel, dim3(ceil_div(C1, CS_C)), dim3(CS_C * CS_S), 0, st, bias_part,
                            (int)(graw_grid.x * graw_grid.y), C1, dbias);
     return check_launch();
 }

@@ -116,24 +116,43 @@ __global__ __launch_bounds__(NB) void bn_nhwc_fwd_stats_kernel(const T *__restri
     block_partials<N>(a, q, lds, CVB, PL, C, part + ((size_t)p.g * gridDim.x + blockIdx.x) * 2 * C);
 }
 
-// ---- partials -> per-channel totals: a block = 16 channels x 16 sub-sums, float64 ---------------------------------
-constexpr int FC = 16, FS = 16;
-__device__ __forceinline__ void channel_totals(const float *__restrict__ part_g, int nblk, int C, int c, double (*lds)[FS][FC],
+// ---- partials -> per-channel totals: a block = 16 channels x 64 sub-sums (1024 threads), float64 -------------------
+// Every thread has at most 8 partials to add (STATS_MAX_BLOCKS / FS): all 16 loads are issued before the first add -- the
+// partials were written a moment ago by blocks on all eight XCDs, each load is a trip through the fabric, and a loop with
+// one load per iteration made this pass (4 blocks for a 64-channel map) the longest of the three.
+constexpr int FC = 16, FS = 64, FU = STATS_MAX_BLOCKS / FS;
+__device__ __forceinline__ void channel_totals(const float *__restrict__ part_g, int nblk, int C, int c, double (*lds)[FS / 4][FC],
                                                double &ta, double &tq)
 {
     const int cl = threadIdx.x % FC, sl = threadIdx.x / FC;
+    float va[FU], vq[FU];
+#pragma unroll
+    for (int i = 0; i < FU; ++i) {
+        const int b = sl + i * FS;
+        const bool ok = c < C && b < nblk;
+        va[i] = ok ? part_g[(size_t)b * 2 * C + c] : 0.f;
+        vq[i] = ok ? part_g[(size_t)b * 2 * C + C + c] : 0.f;
+    }
     double a = 0.0, q = 0.0;
-    if (c < C)
-        for (int b = sl; b < nblk; b += FS) {
-            a += (double)part_g[(size_t)b * 2 * C + c];
-            q += (double)part_g[(size_t)b * 2 * C + C + c];
-        }
-    lds[0][sl][cl] = a;
-    lds[1][sl][cl] = q;
+#pragma unroll
+    for (int i = 0; i < FU; ++i) {
+        a += (double)va[i];
+        q += (double)vq[i];
+    }
+    // the 4 sub-sums a wave holds per channel (lanes cl, cl+16, cl+32, cl+48), then the 16 waves through LDS: fixed order
+    a += __shfl_down(a, 32, 64);
+    q += __shfl_down(q, 32, 64);
+    a += __shfl_down(a, 16, 64);
+    q += __shfl_down(q, 16, 64);
+    if ((threadIdx.x & 63) < FC) {
+        lds[0][threadIdx.x >> 6][cl] = a;
+        lds[1][threadIdx.x >> 6][cl] = q;
+    }
     __syncthreads();
     ta = tq = 0.0;
-    if (sl == 0)
-        for (int s = 0; s < FS; ++s) {
+    if (threadIdx.x < FC)
+#pragma unroll
+        for (int s = 0; s < FS / 4; ++s) {
             ta += lds[0][s][cl];
             tq += lds[1][s][cl];
         }
@@ -146,7 +165,7 @@ __global__ __launch_bounds__(FC *FS) void bn_nhwc_fwd_finalize_kernel(const floa
                                                                        float *__restrict__ save_invstd, float *__restrict__ run_mean,
                                                                        float *__restrict__ run_var)
 {
-    __shared__ double lds[2][FS][FC];
+    __shared__ double lds[2][FS / 4][FC];
     const int c = blockIdx.x * FC + threadIdx.x % FC;
     const bool writer = threadIdx.x < FC && c < C;
     float rm = 0.f, rv = 0.f;
@@ -174,7 +193,7 @@ __global__ __launch_bounds__(FC *FS) void bn_nhwc_bwd_finalize_kernel(const floa
                                                                        float *__restrict__ totals, float *__restrict__ dgamma,
                                                                        float *__restrict__ dbeta)
 {
-    __shared__ double lds[2][FS][FC];
+    __shared__ double lds[2][FS / 4][FC];
     const int c = blockIdx.x * FC + threadIdx.x % FC;
     const bool writer = threadIdx.x < FC && c < C;
     float sa = 0.f, sq = 0.f;

@@ -614,9 +614,7 @@ def _glue_dtype(t, what):
     return _DTYPE_CODE[t.dtype]
 
 
-def is_channels_last(t):
-    """4-D map whose memory is [B][H][W][C] and NOT also [B][C][H][W] (C == 1 or H == W == 1 maps are both: planar)."""
-    return t.dim() == 4 and not t.is_contiguous() and t.is_contiguous(memory_format=_CL)
+from .layout import is_channels_last  # noqa: E402,F401  (re-exported: the layout test every op below dispatches on)
 
 
 def _nhwc_ok(dtype, *channels):

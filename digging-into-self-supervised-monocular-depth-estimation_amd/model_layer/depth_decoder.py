@@ -85,7 +85,10 @@ class DepthDecoder(nn.Module):
         here produces the pre-activation map WITHOUT its bias and the next glue call adds the bias and applies the
         ELU on the way into the padded input of the next convolution (its backward also reduces d(bias)).  Parameters, their names and the results are those of forward()."""
         from mdx import functional as F
+        from mdx.layout import to_layout, weight_layout
         self.outputs = {}
+        cl = weight_layout(self)        # the decoder's own layout (mdx.layout): the encoder's maps are brought to it
+        input_features = [to_layout(f, cl) for f in input_features]
 
         def conv(block, x):     # the stage convolution WITHOUT its bias: the glue call that consumes it adds it
             return TF.conv2d(x, block.conv.conv.weight, None), block.conv.conv.bias

@@ -235,6 +235,7 @@ class ResnetEncoder(nn.Module):
             self.num_ch_enc[1:] *= 4
 
     def forward(self, input_image):
+        from mdx.layout import to_layout, weight_layout
         self.features = []
         x = (input_image - 0.45) / 0.225
         # every map below has two consumers (the next layer's first convolution + its identity path, or the decoder's
@@ -248,6 +249,7 @@ class ResnetEncoder(nn.Module):
         else:
             x = self.encoder.maxpool(stem_b)
         for layer in (self.encoder.layer1, self.encoder.layer2, self.encoder.layer3, self.encoder.layer4):
-            x = _pair(layer(x))
+            # a stage's layout is its weights' layout (mdx.layout): a transposing copy only where two stages differ
+            x = _pair(layer(to_layout(x, weight_layout(layer)) if x[0].is_cuda else x))
             self.features.append(x[0])
         return self.features

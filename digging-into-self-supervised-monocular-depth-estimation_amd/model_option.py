@@ -61,7 +61,9 @@ def options(argv=None):
     p.add_argument("--bucket_mb", type=int, default=0,
                    help="data parallel: size of an all-reduce bucket (0 = one bucket for a captured step, 32 MB eager)")
     p.add_argument("--amp", type=str, default="none", choices=["none", "bf16"])
-    p.add_argument("--channels_last", action="store_true")
+    p.add_argument("--channels_last", type=str, nargs="?", const="all", default="auto",
+                   help='stages whose maps are channels-last (NHWC): "none", "all", "auto" (= mdx.layout.DEFAULT_PLAN, the '
+                        'measured fastest) or a list of stem,layer1..layer4,decoder,pose (mdx/layout.py)')
     p.add_argument("--synthetic_length", type=int, default=768)
     p.add_argument("--max_steps", type=int, default=0, help="stop an epoch early (0 = full epoch)")
     p.add_argument("--miopen_find", action="store_true",

@@ -111,11 +111,17 @@ class setting(object):
                                                      num_frames_to_predict_for=2)
         self.inv_projection = {0: Depth2PointCloud(opt.batch, opt.height, opt.width).to(self.device)}
         self.for_projection = {0: PointCloud2Pixel(opt.batch, opt.height, opt.width).to(self.device)}
-        channels_last = _opt(opt, "channels_last", False)
         for key in self.model:
-            m = self.model[key].to(self.device)
-            if channels_last:
-                m = m.to(memory_format=torch.channels_last)
+            self.model[key] = self.model[key].to(self.device)
+        # which stages keep channels-last maps (mdx.layout: "none", "all", "auto" or a list like "stem,layer1,decoder")
+        from mdx.layout import apply_plan
+        # ("auto" is a GPU plan: the CPU run of the reference-style device pick keeps the reference's planar modules)
+        plan = _opt(opt, "channels_last", "auto")
+        if plan == "auto" and not str(self.device).startswith("cuda"):
+            plan = "none"
+        self.channels_last_stages = apply_plan(self.model, plan)
+        for key in self.model:
+            m = self.model[key]
             # the ResNet classifier head never receives a gradient (the reference keeps it in the optimiser
             # list, loader.py:93-95, where Adam skips it); frozen here so DDP needs no unused-parameter scan
             for name, p in m.named_parameters():

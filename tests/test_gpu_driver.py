@@ -116,7 +116,8 @@ def test_training_trajectory_fused_network_kernels_vs_torch_ops(G, monkeypatch):
             if not native:
                 m.setattr(BatchNorm2d, "fused_min_elements", 1 << 60)          # torch batch_norm + add + relu
                 m.setattr(DepthDecoder, "_glue_ok", lambda self: False)         # ELU / interpolate / cat / pad ops
-                m.setattr(F, "maxpool3s2", lambda x: torch.nn.functional.max_pool2d(x, 3, 2, 1))
+                m.setattr(F, "maxpool3s2", lambda x, fork=False: (lambda y: (y, y) if fork else y)(
+                    torch.nn.functional.max_pool2d(x, 3, 2, 1)))
             torch.manual_seed(0)
             opt = bench.make_opt(2, height=64, width=128)
             opt.batch_pose_pairs = native
@@ -177,7 +178,7 @@ def test_kitti_tree_training_and_eigen_style_evaluation(G, tmp_path):
     assert 0 <= res["a1"] <= res["a2"] <= res["a3"] <= 1
 
 
-def _trainer_losses(graph, automask=False, noise="device", n=6, lr_change_at=4, amp="none", channels_last=False, batches=None,
+def _trainer_losses(graph, automask=False, noise="device", n=6, lr_change_at=4, amp="none", channels_last="auto", batches=None,
                     frame_ids=(0, -1, 1)):
     import importlib
     bench = importlib.import_module("bench")
@@ -209,6 +210,22 @@ def _same_trajectory(a, b):
     assert all(np.isfinite(a)) and all(np.isfinite(b)), (a, b)
     np.testing.assert_allclose(a[:3], b[:3], rtol=2e-4, atol=1e-6)     # float32 rounding / atomics-order differences ...
     np.testing.assert_allclose(a, b, rtol=1e-2, atol=1e-5)             # ... which Adam amplifies step by step
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_trainer_channels_last_follows_the_planar_trajectory(G, graph):
+    """The layout plan (mdx/layout.py) changes where the bytes of a map lie, not the numbers: six steps with every stage
+    channels-last (csrc/norm_nhwc.hip, glue_nhwc.hip between MIOpen's NHWC convolutions), with a mixed plan (a transposing
+    copy where stages of different layout meet) and with planar maps follow one trajectory -- eager and captured."""
+    planar, n0, _ = _trainer_losses(graph, channels_last="none")
+    nhwc, n1, tr = _trainer_losses(graph, channels_last="all")
+    mixed, n2, _ = _trainer_losses(graph, channels_last="stem,layer2,decoder")
+    assert n0 == n1 == n2 == 6
+    assert tr.setting.channels_last_stages == frozenset(("stem", "layer1", "layer2", "layer3", "layer4", "decoder", "pose"))
+    enc = tr.setting.raw_model["encoder"].encoder
+    assert enc.layer2[0].conv1.weight.is_contiguous(memory_format=torch.channels_last) and not enc.layer2[0].conv1.weight.is_contiguous()
+    _same_trajectory(nhwc, planar)
+    _same_trajectory(mixed, planar)
 
 
 def test_trainer_graph_replay_matches_eager(G):
@@ -323,14 +340,14 @@ def test_trainer_channels_last_data_parallel_fused_adam(G):
     steps (1-rank RCCL group) follow the single-process steps."""
     import torch.distributed as dist
     import bench
-    plain, _, tr_p = _trainer_losses(False, channels_last=True)
+    plain, _, tr_p = _trainer_losses(False, channels_last="all")
     assert tr_p.setting.sync is None
     assert any(p.dim() == 4 and not p.is_contiguous() for p in tr_p.setting.parameters)
     dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % bench.free_port(), rank=0, world_size=1,
                             device_id=torch.device(torch.cuda.current_device()))
     try:
         # the same batches (a process group brings a DistributedSampler: another order)
-        dp, _, tr_d = _trainer_losses(False, channels_last=True, batches=tr_p.last_batches)
+        dp, _, tr_d = _trainer_losses(False, channels_last="all", batches=tr_p.last_batches)
         sync = tr_d.setting.sync
         assert sync is not None
         assert all(p.grad.stride() == p.stride() and p.grad.data_ptr() == sync.flat.data_ptr() + 4 * sync.offsets[id(p)]
