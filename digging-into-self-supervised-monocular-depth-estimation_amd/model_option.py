@@ -54,6 +54,9 @@ def options(argv=None):
                    help="synthetic dataset hands over KITTI-sized decoded frames (1242x375 uint8), as the KITTI loaders do with gpu_image_prep")
     p.add_argument("--resume", type=int, default=0,
                    help="restart after this many finished epochs from ./model_save/<save>/ (weights <key><N>.pt + state<N>.pt)")
+    p.add_argument("--synthetic_geometry", action="store_true",
+                   help="synthetic dataset: frames rendered from one rigid textured scene at known poses, ground truth = its "
+                        "depth (model_tool/synthetic.py: scene) -- for tests of what the step learns")
     p.add_argument("--synthetic_pool", type=int, default=0, help="synthetic dataset: number of distinct samples kept (0 = all)")
     p.add_argument("--noise", type=str, default="device", choices=["device", "cpu"])
     p.add_argument("--grad_comm", type=str, default="fp32", choices=["fp32", "bf16"],

@@ -70,7 +70,7 @@ class setting(object):
                                      seed=0 if is_training else 1, pool=_opt(opt, "synthetic_pool", 0),
                                      uint8=_opt(opt, "uint8_loader", False),
                                      raw=gpu_image_prep(opt, self.device) and _opt(opt, "synthetic_raw", False),
-                                     is_training=is_training)
+                                     is_training=is_training, geometry=_opt(opt, "synthetic_geometry", False))
         else:
             from model_loader import KITTIMonoDataset_v2, KITTIMonoStereoDataset
             from model_utility import readlines

@@ -192,7 +192,10 @@ def test_decoder_glue_path_equals_module_path(amp, cl):
 @pytest.mark.parametrize("cfg", [(12, 64, 48, 160, True, True), (3, 7, 5, 9, False, True), (2, 16, 96, 320, False, True),
                                  (4, 32, 6, 20, True, False), (2, 8, 3, 3, False, False), (1, 5, 130, 67, True, True),
                                  (1, 8, 130, 67, True, True), (3, 24, 5, 9, True, True), (2, 512, 3, 5, False, True),
-                                 (1, 2048, 2, 3, True, True), (5, 40, 1, 1, False, False)])
+                                 (1, 2048, 2, 3, True, True), (5, 40, 1, 1, False, False),
+                                 # channels-last one-launch form (>= 256 channels, rows that fit the forward's registers): full / partial
+                                 # last sweep, a single row
+                                 (12, 256, 12, 40, True, True), (3, 256, 7, 9, False, True), (2, 512, 2, 3, True, False)])
 def test_bn_act_matches_torch(F, cfg, dtype, cl):
     """bn_act == relu(batch_norm(x, training=True) + residual): output, running statistics, all four gradients,
     against torch's CPU batch norm in float64 (MIOpen's GPU batch norm drops elements for H*W % 4 != 0 planes --
@@ -326,7 +329,7 @@ def test_batched_pose_pairs_equal_the_loop_on_gpu():
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("cl", [False, True])
-@pytest.mark.parametrize("shape", [(6, 8, 12, 40), (4, 16, 96, 320)])      # single-launch path, two-pass path
+@pytest.mark.parametrize("shape", [(6, 8, 12, 40), (4, 16, 96, 320), (4, 256, 6, 20)])      # single-launch / multi-launch paths
 def test_bn_act_groups_equal_separate_calls(F, shape, dtype, cl):
     """bn_act(groups=2) on a batch == bn_act on its two halves one after the other (outputs, running statistics,
     gradients): what lets both frame pairs go through the pose network in one batch."""
