@@ -175,7 +175,10 @@ def cpu_baseline(batch=4, steps=10):
 
 
 # written by tools/pmc_bench.sh + tools/pmc_to_json.py: one file per BASELINE workload shape (configs[1], [4], [3])
-PMC_FILES = [os.path.join(ROOT, "profiles", n) for n in ("r04_bench_kernel_pmc.json", "r04_pmc_c4.json", "r04_pmc_c3.json")]
+PMC_FILES = [os.path.join(ROOT, "profiles", n) for n in ("r05_bench_kernel_pmc.json", "r05_pmc_c4.json", "r05_pmc_c3.json")]
+# written by tools/issue_bound.py (no GPU needed): the training kernel's loop mix priced with the measured issue cycles per class
+ISSUE_BOUND_FILE = os.path.join(ROOT, "profiles", "r05_issue_bound.json")
+SIMDS, CLOCK_MHZ = 1024, 2400.0          # MI355X: 256 CUs x 4 SIMDs; the clock the micro-benchmarks' cycle prices assume
 
 
 def roofline_blocks(args, opt, frame_ids, tsum):
@@ -205,16 +208,16 @@ def roofline_blocks(args, opt, frame_ids, tsum):
     # paths -- by the hash of its sources and flags, and to the workload by its shape; anything else reports null rather
     # than a stale number.
     traffic = issue = None
+    import hashlib
+    import importlib.util
+    from mdx import LIB_PATH
+    spec = importlib.util.spec_from_file_location("_mdx_build", os.path.join(os.path.dirname(LIB_PATH), "build.py"))
+    _build = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(_build)
     try:
-        import hashlib
         want = [args.batch, opt.height, opt.width, nS, nsc]
         pmc = next(d for d in (json.load(open(f)) for f in PMC_FILES if os.path.exists(f)) if d.get("shape") == want)
-        from mdx import LIB_PATH
         so = hashlib.sha256(open(LIB_PATH, "rb").read()).hexdigest()[:16]
-        import importlib.util
-        spec = importlib.util.spec_from_file_location("_mdx_build", os.path.join(os.path.dirname(LIB_PATH), "build.py"))
-        _build = importlib.util.module_from_spec(spec)
-        spec.loader.exec_module(_build)
         same_build = pmc.get("lib_sha16") == so or (pmc.get("source_sha16") == _build.source_sha16()
                                                     and "MDX_LIB" not in os.environ)
         ent = next((v for kk, v in pmc["kernels"].items() if kk.startswith(k[dom]["name"].split("<")[0])
@@ -228,17 +231,30 @@ def roofline_blocks(args, opt, frame_ids, tsum):
     except (OSError, ValueError, KeyError, StopIteration):
         pass
     launch_us = 1e3 * k[dom]["ms"]
-    # share of the launch during which the SIMDs' vector ALUs are occupied (SQ_ACTIVE_INST_VALU, 4 cycles per unit): the
-    # roof this kernel actually sits under -- ~1.0 means every VALU instruction removed shortens the launch in proportion
-    valu_busy = (issue["valu_busy_us"] / issue["kernel_us_profiled"]) if issue and issue.get("valu_busy_us") and issue.get("kernel_us_profiled") else None
     hbm_frac = k[dom]["GBs"] / HBM_PEAK_GBS
+    # What bounds this kernel is vector-instruction ISSUE, not HBM: measured = SQ_INSTS_VALU / (SIMDs x launch
+    # cycles), wave-instructions per SIMD-cycle, from the committed counter pass; bound = 1 / (mean issue cycles of the loop's
+    # instruction mix), tools/issue_bound.py (static ISA mix x per-class cycles measured with tools/int_rate.hip).  Both are
+    # tied to this build by the source hash and are null otherwise.
+    valu_rate = bound = None
+    if issue and issue.get("valu_wave_insts") and issue.get("kernel_us_profiled"):
+        valu_rate = issue["valu_wave_insts"] / (SIMDS * issue["kernel_us_profiled"] * CLOCK_MHZ)
+    try:
+        ib = json.load(open(ISSUE_BOUND_FILE))
+        if ib.get("source_sha16") == _build.source_sha16() and ("<%d" % nS) in k[dom]["name"] and "ILi%d" % nS in ib.get("kernel", ""):
+            bound = ib["issue_bound_inst_per_simd_cycle"]
+    except (OSError, ValueError, KeyError):
+        pass
     out = {"roofline": {"kernel": k[dom]["name"],
                         "bound": "hbm",        # the roofline `frac` is quoted against (BASELINE.json: HBM roofline of this kernel)
-                        "limiter": (None if valu_busy is None else ("valu" if valu_busy > hbm_frac else "hbm")),
                         "achieved": k[dom]["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": hbm_frac, "valu_busy_frac": valu_busy, "traffic": traffic,
-                        "traffic_source": (None if traffic is None else "committed rocprofv3 --pmc passes over this command (profiles/r04_*; "
+                        "frac": hbm_frac, "traffic": traffic,
+                        # measured HBM bytes (the counters' FETCH + WRITE, corrected as the guide prescribes) over the same launch time
+                        "traffic_frac": (None if traffic is None else traffic / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBS),
+                        "traffic_source": (None if traffic is None else "committed rocprofv3 --pmc passes over this command (profiles/r05_*; "
                                            "tied to this library build and workload shape by hash), not measured in this run"),
+                        "valu_inst_per_simd_cycle": valu_rate, "issue_bound_inst_per_simd_cycle": bound,
+                        "issue_frac": (valu_rate / bound if valu_rate and bound else None),
                         "issue": issue,
                         "launch_us": launch_us, "alg_bytes_per_launch": k[dom]["bytes"],
                         "launches_timed": k[dom]["launches"],
@@ -249,6 +265,64 @@ def roofline_blocks(args, opt, frame_ids, tsum):
     if others:
         out["roofline_other"] = [{"kernel": k[n]["name"], "achieved": k[n]["GBs"], "frac": k[n]["GBs"] / HBM_PEAK_GBS,
                                   "launch_us": 1e3 * k[n]["ms"], "alg_bytes_per_launch": k[n]["bytes"]} for n in others]
+    return out
+
+
+def network_kernel_roofline(args, opt):
+    """`roofline_other` entries of the hand-written kernels BETWEEN the convolutions (batch norm + add + ReLU, decoder glue):
+    streaming kernels, for which the HBM roof is the right roof.  Measured live on the step's own largest maps in the layout
+    the step uses: K calls captured in a hipGraph and replayed (GPU time per call including the gaps between its launches),
+    bytes = every map once per pass that has to touch it (forward x [+ res] -> y: 2-3 N; backward dy, y, x -> dx [+ dres]:
+    4-5 N).  The whole family per shape: tools/netbench.py -> profiles/r05_netbench_*.txt."""
+    from mdx import functional as F
+    from mdx.layout import parse_plan
+    cl = "layer1" in parse_plan(opt.channels_last if opt.channels_last != "auto" else None) or opt.channels_last in ("auto", "all", True)
+    dt = torch.bfloat16 if args.amp == "bf16" else torch.float32
+    fmt = torch.channels_last if cl else torch.contiguous_format
+    K, B = 8, args.batch
+
+    def graph_us(fn):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(K):
+                fn()
+        g.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            g.replay()
+        e1.record()
+        e1.synchronize()
+        return 1e3 * e0.elapsed_time(e1) / (10 * K)
+
+    out = []
+    widths = (64, 64) if args.num_layers < 50 else (64, 256)
+    for name, C, h, w, has_res in (("stem", widths[0], args.height // 2, args.width // 2, False),
+                                   ("layer1", widths[1], args.height // 4, args.width // 4, True)):
+        x = torch.randn(B, C, h, w, device="cuda").to(dt).contiguous(memory_format=fmt).requires_grad_(True)
+        res = torch.randn(B, C, h, w, device="cuda").to(dt).contiguous(memory_format=fmt).requires_grad_(True) if has_res else None
+        wt, bs = torch.ones(C, device="cuda", requires_grad=True), torch.zeros(C, device="cuda", requires_grad=True)
+        rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+        gy = torch.randn(B, C, h, w, device="cuda").to(dt).contiguous(memory_format=fmt)
+        ins = [x, wt, bs] + ([res] if has_res else [])
+
+        def fwd():
+            return F.bn_act(x, wt, bs, rm, rv, 1e-5, 0.1, residual=res, relu=True)
+        tf = graph_us(fwd)
+        tfb = graph_us(lambda: torch.autograd.grad(fwd(), ins, gy))
+        n = x.numel() * x.element_size()
+        nbytes = n * ((2 + has_res) + (4 + has_res))
+        out.append({"kernel": "mdx::%sbn_* forward + backward (%s map %dx%dx%dx%d, %s, %s)" % (
+                        "nhwc::" if cl else "", name, B, C, h, w, "channels-last" if cl else "planar", str(dt).split(".")[-1]),
+                    "achieved": nbytes / tfb / 1e3, "frac": nbytes / tfb / 1e3 / HBM_PEAK_GBS, "unit": "GB/s", "bound": "hbm",
+                    "us_forward": tf, "us_backward": tfb - tf, "alg_bytes": nbytes,
+                    "timing": "hipGraph replay of %d calls, HIP events, live in this run" % K})
     return out
 
 
@@ -306,6 +380,7 @@ def trainer_loop(args, frame_ids, steps, warmup, workers, raw):
                    amp=args.amp, workers=workers)
     opt.fused_train = not args.per_scale_kernels
     opt.grad_comm, opt.bucket_mb = args.grad_comm, args.bucket_mb
+    opt.channels_last = args.channels_last
     world = int(os.environ.get("WORLD_SIZE", "1"))
     opt.synthetic_length = (steps + warmup + 4) * args.batch * world
     opt.synthetic_pool = 4 * args.batch          # the stand-in dataset must not be what is measured
@@ -550,8 +625,15 @@ def main():
         torch.cuda.synchronize()
         F.TIMING = None
     ranks_verified = 1
+    rank_ms = [1e3 * dt / args.steps]
     if distributed:
         tdev = device if backend == "nccl" else "cpu"
+        # every rank's own time over the timed steps: the line's value uses the MAX (the contract); min / max side by side
+        # make a straggler visible in the first multi-GPU record
+        mine = torch.tensor([dt], device=tdev, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(every, mine)
+        rank_ms = [1e3 * float(t[0]) / args.steps for t in every]
         tmax = torch.tensor([dt], device=tdev, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax[0])
@@ -576,6 +658,8 @@ def main():
                                       str(frame_ids).replace(" ", ""), "fp32" if args.amp == "none" else "bf16 nets"),
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world},
             "ranks_verified": ranks_verified, "final_loss": loss_val, "hip_graph": bool(graph is not None), "miopen_find_db": bool(miopen_db),
+            "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms), "argmax_rank": int(max(range(len(rank_ms)), key=rank_ms.__getitem__))},
+            "channels_last": sorted(getattr(st, "channels_last_stages", ())),
         }
         if st.sync is not None:
             line["gradient_exchange"] = {"backend": "rccl" if st.sync.backend == "nccl" else st.sync.backend,
@@ -584,6 +668,10 @@ def main():
                                          "what": "flat gradient buffer; bucketed all-reduce(mean) issued from inside backward"}
         if not args.no_roofline and timing is not None:
             line.update(roofline_blocks(args, opt, frame_ids, F.timing_summary(timing)))
+            try:
+                line.setdefault("roofline_other", []).extend(network_kernel_roofline(args, opt))
+            except Exception as exc:  # noqa: BLE001  (a side measurement never takes the line down)
+                line.setdefault("roofline_other", []).append({"error": "network kernel measurement failed: %r" % (exc,)})
     if not args.no_trainer_loop and (graph is None or distributed):
         graph = None
         del tr, st, cp, inputs
@@ -607,6 +695,8 @@ def main():
             failed = failed or ("error" in res and world == 1)
             if rank == 0:
                 line[key] = res
+                if "error" in res:
+                    line["degraded"] = True       # a measurement this line names did not run (several ranks: reported, exit code 0)
                 if "value" in res:
                     res["vs_resident"] = res["value"] / line["value"]
     if rank == 0:

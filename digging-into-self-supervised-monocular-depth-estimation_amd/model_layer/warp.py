@@ -4,35 +4,31 @@ hand-written gfx950 kernels through libmdx_hip.so.
     interpolate, grid_sample, upsample, disparity2depth, vector2translation, angle2rotation,
     param2matrix, Depth2PointCloud, PointCloud2Pixel
 
-GPU float32 only: a CPU tensor raises (there is no CPU fallback).  Modes the training path never uses
-(non-bilinear interpolate, other grid_sample paddings) are forwarded to torch's own GPU kernels.
+GPU tensors always take the kernels (and raise if libmdx_hip.so is missing -- there is no fallback for them).  CPU tensors --
+the reference's own device pick on a machine without a GPU, model_train.py:28; BASELINE configs[0] -- take this package's
+plain-PyTorch restatement of the same op sequences (mdx/composite.py): a dispatch on the tensor's device, never on whether
+the library loaded.  Modes the training path never uses (non-bilinear interpolate, other grid_sample paddings) are forwarded
+to torch.
 """
 import torch
 import torch.nn as nn
 import torch.nn.functional as TF
 
+from mdx import composite as C
 from mdx import functional as F
-from mdx._lib import MdxError
-
-
-def _require_gpu(t, what):
-    if not t.is_cuda:
-        raise MdxError("%s: expected a CUDA/HIP tensor, got %s (this build has no CPU fallback)" % (what, t.device))
 
 
 def grid_sample(tensor, coords, padding_mode, align_corners):
     """reference: model_layer/warp.py:12-14 (bilinear)."""
-    _require_gpu(tensor, "grid_sample")
     if padding_mode == "border" and align_corners:
-        return F.grid_sample_border(tensor, coords)
+        return F.grid_sample_border(tensor, coords) if tensor.is_cuda else C.grid_sample_border(tensor, coords)
     return TF.grid_sample(tensor, coords, padding_mode=padding_mode, align_corners=align_corners)
 
 
 def interpolate(tensor, height, width, mode, align_corners):
     """reference: model_layer/warp.py:18-20."""
-    _require_gpu(tensor, "interpolate")
     if mode == "bilinear" and not align_corners and tensor.dim() == 4:
-        return F.interpolate_bilinear(tensor, height, width)
+        return F.interpolate_bilinear(tensor, height, width) if tensor.is_cuda else C.interpolate_bilinear(tensor, height, width)
     if mode in ("nearest", "area", "nearest-exact"):
         return TF.interpolate(tensor, [height, width], mode=mode)
     return TF.interpolate(tensor, [height, width], mode=mode, align_corners=align_corners)
@@ -45,7 +41,8 @@ def upsample(tensor):
 
 def disparity2depth(disparity, min_depth, max_depth):
     """reference: model_layer/warp.py:29-39 -> (scaled_disp, depth)."""
-    _require_gpu(disparity, "disparity2depth")
+    if not disparity.is_cuda:
+        return C.disparity2depth(disparity, min_depth, max_depth)
     return F.disparity2depth(disparity, min_depth, max_depth)
 
 
@@ -105,8 +102,10 @@ class Depth2PointCloud(nn.Module):
         self.batch_size, self.height, self.width = batch_size, height, width
 
     def forward(self, depth, inverse_intrinsic_matrix):
-        _require_gpu(depth, "Depth2PointCloud")
-        return F.backproject(depth.reshape(-1, 1, self.height, self.width), inverse_intrinsic_matrix)
+        depth = depth.reshape(-1, 1, self.height, self.width)
+        if not depth.is_cuda:
+            return C.backproject(depth, inverse_intrinsic_matrix)
+        return F.backproject(depth, inverse_intrinsic_matrix)
 
 
 class PointCloud2Pixel(nn.Module):
@@ -117,6 +116,7 @@ class PointCloud2Pixel(nn.Module):
         self.batch_size, self.height, self.width, self.eps = batch_size, height, width, eps
 
     def forward(self, camera_coords, intrinsic_matrix, transformation_matrix):
-        _require_gpu(camera_coords, "PointCloud2Pixel")
+        if not camera_coords.is_cuda:
+            return C.project(camera_coords, intrinsic_matrix, transformation_matrix, self.height, self.width, self.eps)
         P = F.compose_projection(intrinsic_matrix, transformation_matrix)
         return F.project(camera_coords, P, self.height, self.width, self.eps)

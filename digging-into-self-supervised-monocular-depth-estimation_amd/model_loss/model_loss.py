@@ -1,14 +1,11 @@
 """Loss modules with the reference's names and call signatures (model_loss/model_loss.py:11-116),
-backed by gfx950 kernels through libmdx_hip.so.  GPU float32 only -- no CPU fallback."""
+backed by gfx950 kernels through libmdx_hip.so for GPU tensors (no fallback for them: a missing library raises); CPU
+tensors -- the reference's device pick on a machine without a GPU, BASELINE configs[0] -- take the package's plain-PyTorch
+restatement of the same op sequences (mdx/composite.py)."""
 import torch.nn as nn
 
+from mdx import composite as C
 from mdx import functional as F
-from mdx._lib import MdxError
-
-
-def _require_gpu(t, what):
-    if not t.is_cuda:
-        raise MdxError("%s: expected a CUDA/HIP tensor, got %s (this build has no CPU fallback)" % (what, t.device))
 
 
 class SSIM(nn.Module):
@@ -22,15 +19,15 @@ class SSIM(nn.Module):
         self.C2 = 0.03 ** 2
 
     def forward(self, image1, image2):
-        _require_gpu(image1, "SSIM")
-        return F.ssim(image1, image2)
+        return F.ssim(image1, image2) if image1.is_cuda else C.ssim(image1, image2)
 
 
 class EdgeAwareSmooth(nn.Module):
     """reference: model_loss/model_loss.py:45-88 (no mean-normalisation)."""
 
     def forward(self, disparity, image):
-        _require_gpu(disparity, "EdgeAwareSmooth")
+        if not disparity.is_cuda:
+            return C.smooth_loss(disparity, image, normalize=False)
         return F.smooth_loss(disparity, image, normalize=False)
 
 
@@ -42,7 +39,8 @@ class ReprojectionLoss(nn.Module):
         self.ssim = SSIM()
 
     def forward(self, prediction, target):
-        _require_gpu(prediction, "ReprojectionLoss")
+        if not prediction.is_cuda:
+            return C.reprojection_loss(prediction, target)
         return F.reprojection_loss(prediction, target)
 
 
@@ -54,5 +52,6 @@ class SmoothLoss(nn.Module):
         self.edge_aware_smooth = EdgeAwareSmooth()
 
     def forward(self, disp, color):
-        _require_gpu(disp, "SmoothLoss")
+        if not disp.is_cuda:
+            return C.smooth_loss(disp, color, normalize=True)
         return F.smooth_loss(disp, color, normalize=True)

@@ -54,6 +54,11 @@ class compute(object):
         self.num_pose_frames = len(opt.frame_ids) if opt.pose_frames == "all" else 2
         self.fused = _opt(opt, "fused", True)
         self.fused_train = _opt(opt, "fused_train", True)
+        if not str(device).startswith("cuda"):
+            # the reference's device pick on a machine without a GPU (model_train.py:28; BASELINE configs[0]): the fused entries are
+            # GPU kernels, so the CPU run takes the reference-shaped op-by-op path, whose ops dispatch CPU tensors to the package's
+            # plain-PyTorch restatement (mdx/composite.py)
+            self.fused = False
         # "device": N(0,1) drawn on the GPU; "cpu": the reference's torch.randn on the host + H2D copy
         # (processor.py:195) -- same stream of numbers as the reference for a given torch seed.
         self.noise_mode = _opt(opt, "noise", "device")

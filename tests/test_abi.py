@@ -123,14 +123,18 @@ def test_round4_workspace_contracts():
     assert lib.mdx_smooth_loss_multi(4, 12, hs, ws, arr, arr, 1, fake, None, fake, C.c_size_t(one), None) in (-2, -3)
 
 
-def test_cpu_tensors_are_refused_loudly():
+def test_kernel_entry_points_refuse_cpu_tensors_loudly():
+    """The kernel layer (mdx.functional -> libmdx_hip.so) never computes anything on the host: a CPU tensor raises.  (The
+    reference-named ops one level up, model_layer / model_loss, dispatch CPU tensors to the package's plain-PyTorch composite --
+    by the tensor's device, tests/test_cpu_dispatch.py -- and GPU tensors to these entry points, with no way back.)"""
     import torch
     from mdx import functional as F
     with pytest.raises(_lib.MdxError):
         F.reprojection_loss(torch.rand(1, 3, 8, 8), torch.rand(1, 3, 8, 8))
-    import model_layer
     with pytest.raises(_lib.MdxError):
-        model_layer.disparity2depth(torch.rand(1, 1, 8, 8), 0.1, 100)
+        F.disparity2depth(torch.rand(1, 1, 8, 8), 0.1, 100)
+    with pytest.raises(_lib.MdxError):
+        F.bn_act(torch.rand(2, 8, 4, 4), torch.ones(8), torch.zeros(8), None, None)
 
 
 def test_graft_entry_build():

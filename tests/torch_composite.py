@@ -1,34 +1,18 @@
 """TEST INFRASTRUCTURE: the loss path of one training step as plain PyTorch ops -- this build's own restatement of
 compute.image2warping + compute.compute_loss (reference processor.py:139-218 with warp.py:12-39,193-269 and
-model_loss.py:11-116), runnable on CPU tensors.  bench.py's cpu_baseline times it beside the oracle (SURVEY 8d asks for
-both lines); tests/test_torch_composite.py checks it against the reference-made goldens.  Never imported by the product."""
+model_loss.py:11-116), runnable on CPU tensors, assembled from the package's own CPU op restatements (mdx/composite.py).
+bench.py's cpu_baseline times it beside the oracle (SURVEY 8d asks for both lines); tests/test_torch_composite.py checks it
+against the reference-made goldens.  Never imported by the product."""
+import importlib
+
 import torch
 import torch.nn.functional as F
 
-
-def ssim(x, y):
-    x, y = F.pad(x, (1, 1, 1, 1), mode="reflect"), F.pad(y, (1, 1, 1, 1), mode="reflect")
-    mu_x, mu_y = F.avg_pool2d(x, 3, 1), F.avg_pool2d(y, 3, 1)
-    sig_x = F.avg_pool2d(x * x, 3, 1) - mu_x * mu_x
-    sig_y = F.avg_pool2d(y * y, 3, 1) - mu_y * mu_y
-    sig_xy = F.avg_pool2d(x * y, 3, 1) - mu_x * mu_y
-    n = (2 * mu_x * mu_y + 0.01 ** 2) * (2 * sig_xy + 0.03 ** 2)
-    d = (mu_x ** 2 + mu_y ** 2 + 0.01 ** 2) * (sig_x + sig_y + 0.03 ** 2)
-    return torch.clamp((1 - n / d) / 2, 0, 1)
+importlib.import_module("digging-into-self-supervised-monocular-depth-estimation_amd")
 
 
-def reprojection_loss(pred, target):
-    l1 = torch.abs(target - pred).mean(1, True)
-    return 0.85 * ssim(pred, target).mean(1, True) + 0.15 * l1
-
-
-def smooth_loss(disp, color):
-    disp = disp / (disp.mean(2, True).mean(3, True) + 1e-7)
-    gx = torch.abs(disp[:, :, :, :-1] - disp[:, :, :, 1:])
-    gy = torch.abs(disp[:, :, :-1, :] - disp[:, :, 1:, :])
-    gx = gx * torch.exp(-torch.abs(color[:, :, :, :-1] - color[:, :, :, 1:]).mean(1, True))
-    gy = gy * torch.exp(-torch.abs(color[:, :, :-1, :] - color[:, :, 1:, :]).mean(1, True))
-    return gx.mean() + gy.mean()
+# the op-level restatements live in the package (mdx/composite.py: what model_layer / model_loss dispatch CPU tensors to)
+from mdx.composite import reprojection_loss, smooth_loss, ssim  # noqa: E402,F401
 
 
 def warp(disp, source, K, invK, T, H, W, min_depth=0.1, max_depth=100.0):
