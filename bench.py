@@ -171,6 +171,30 @@ def cpu_baseline(batch=4, steps=10):
             fn()
         out["loss_path_" + name] = {"value": batch * reps / (time.perf_counter() - t0), "unit": "images/s",
                                     "sample": "loss path only (4 scales, forward + backward), batch %d x %d" % (batch, reps)}
+    # BASELINE configs[0] through the PRODUCT: setting / compute on the "cpu" device (the reference's device pick on a machine
+    # without a GPU, model_train.py:28) -- torch-CPU networks + the package's plain-PyTorch op composite (mdx/composite.py),
+    # the reference-shaped op-by-op path; nothing from oracle/
+    from model_tool import setting, compute
+    opt = make_opt(batch, height=H, width=W)
+    opt.synthetic_length = batch
+    torch.manual_seed(0)
+    st, cp = setting(opt, "cpu"), compute(opt, "cpu")
+    st.set_train()
+    reps = 3
+    for step in range(reps + 1):
+        if step == 1:
+            t0 = time.perf_counter()
+        o = {}
+        i, o = cp.forward_depth(dict(inputs), o, st)
+        i, o = cp.forward_pose(i, o, st)
+        i, o = cp.image2warping(i, o, st)
+        o = cp.compute_loss(i, o, st)
+        st.optim["optimizer"].zero_grad(set_to_none=True)
+        o["loss"].backward()
+        st.optim["optimizer"].step()
+    out["product_cpu_step"] = {"value": batch * reps / (time.perf_counter() - t0), "unit": "images/s", "cores": torch.get_num_threads(),
+                               "sample": "configs[0]: batch %d x %d steps after 1 warm-up through model_tool.setting / compute on "
+                                         "device 'cpu' (torch-CPU nets + mdx/composite.py)" % (batch, reps)}
     return out
 
 

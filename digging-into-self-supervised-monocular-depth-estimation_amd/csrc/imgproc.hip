@@ -208,10 +208,7 @@ __global__ __launch_bounds__(256) void resample_h_kernel(ResampleLaunch L)
 // v_readlane of 8 cycles each and ~25 instructions of bookkeeping against 43 LDS instructions in that first form; see
 // hw_taps below for what round 4 made of the tap loop).
 constexpr int HW_ROWS = 64;
-#ifndef MDX_HW_ROWT
-#define MDX_HW_ROWT 1
-#endif
-constexpr int HW_ROWT = MDX_HW_ROWT;        // 64-row tiles per block, one after the other (A/B builds: -DMDX_HW_ROWT=2 ...)
+constexpr int HW_ROWT = 1;                  // 64-row tiles per block, one after the other (2 / 3 / 6 tiles measured no faster: below)
 constexpr int HW_LDS_BUDGET = 32 * 1024;    // preferred LDS per block (5-6 blocks per CU).  Re-swept on the round-4 kernel (tools/r4_rows_lds.sh,
                                             // stage time per batch): 24 KB 151 us, 32 KB 132-134 (32 / 16 / 8 / 4 columns per block at the four
                                             // scales), 40 KB 134-137 (32 / 32 / 16 / 4), 45-56 KB 133-135 (64 / 32 / 16 / 8), 64 KB 153
@@ -231,16 +228,11 @@ static __device__ __forceinline__ int mad24s(int a, int w, int c)
 // tools/smem_test.hip).  The compiler does not see the load: the wait is part of the statement.
 static __device__ __forceinline__ i32x16_t sload16(const int *p)
 {
-#ifdef MDX_HW_SLOAD_ASM
-    i32x16_t v;
-    asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p));
-    return v;
-#else
     // a uniform pointer into the CONSTANT address space: the compiler selects s_load_dwordx16 itself and accounts for it in its
-    // own s_waitcnt bookkeeping, so the load may stay in flight across the LDS reads that follow
+    // own s_waitcnt bookkeeping, so the load may stay in flight across the LDS reads that follow (an inline-asm s_load with its
+    // own s_waitcnt lgkmcnt(0), round 4's first form, could not)
     typedef const i32x16_t __attribute__((address_space(4), aligned(4))) *cptr;
     return *(cptr)(unsigned long long)p;
-#endif
 }
 
 // Round 4 (late): TWO neighbouring columns per pass, weights in scalar registers.  The windows of neighbouring output columns
@@ -290,7 +282,9 @@ static __device__ __forceinline__ void resample_h_rows(const PackedJob &J, const
     const int px_lo = FLIP ? last - hi_max : lo_min, px_hi = FLIP ? last - lo_min : hi_max;
     const int a0 = (3 * px_lo) & ~15;
     const int nch = min((3 * px_hi + 3 - a0 + 15) >> 4, (pitch - 12) >> 4);
-    const unsigned total = (unsigned)in_h * (unsigned)J.in_stride;            // bytes of the image's rows (its slot may be larger)
+    // readable bytes of the image: the LAST row ends at 3 * in_w, not at in_stride (a bottom-right crop view of a larger image has
+    // nothing behind it; the chunk that straddles the end is repaired by the shift below)
+    const unsigned total = (unsigned)(in_h - 1) * (unsigned)J.in_stride + 3u * (unsigned)J.in_w;
     // Every global load of the set-up is issued before the first LDS write that depends on one.  The first form staged chunk by
     // chunk -- `if (inside) 16-byte load else byte-wise tail`, then the LDS write, per pass of a 4 x (1..4)-pass loop nest -- and
     // the compiler put s_waitcnt vmcnt(0) behind each load: 4 to 16 memory round trips in a row per block
@@ -312,10 +306,10 @@ static __device__ __forceinline__ void resample_h_rows(const PackedJob &J, const
     // A block walks HW_ROWT tiles of 64 rows one after the other (same columns: bounds, span and table rows are set up once).
     // Measured twice, before and after the set-up's loads were batched (image preparation per batch, graph replay): 1 / 2 / 3 / 6
     // tiles per block 141.9 / 143.7 / 143.5 / 148.4 us -- fewer, longer blocks buy nothing, so a block takes ONE tile; the loop
-    // stays for A/B builds.  (No barrier is needed between tiles: the staging of tile k + 1 writes the span rows, which every
+    // stays.  (No barrier is needed between tiles: the staging of tile k + 1 writes the span rows, which every
     // wave finished reading before the barrier in front of tile k's stores; its tap loop writes the result tile behind the
     // barrier that follows the staging, i.e. after every wave's stores of tile k.)
-    // Phase switches of development builds: -DMDX_HW_NOSTAGE (no staging loads), -DMDX_HW_NOTAPS=n (at most n taps).  Per batch:
+    // Phase by phase (development builds without the staging loads / with at most n taps; LABNOTES.md, round 4), per batch:
     // block skeleton + stores 11 us, + staging 21 us (162 MB of spans through the L2: the source is re-read 3.2 x), + taps 44 us,
     // all three 67 us: staging and taps overlap by 9 us only.  Loading tile k + 1's first two chunk columns into registers BEFORE
     // tile k's tap loop and writing them to the span rows behind it (2 / 3 tiles per block) measured 146.1 / 141.4 us against
@@ -350,7 +344,6 @@ static __device__ __forceinline__ void resample_h_rows(const PackedJob &J, const
     // 16 lanes per row, 16 rows per sweep (no division by run-time values anywhere in this kernel: an emulated integer
     // division is ~40 vector instructions -- the first version spent more of them on its index arithmetic than on the taps)
     auto stage_tile = [&](int yb, int ch_first) {
-#ifndef MDX_HW_NOSTAGE
         if (total >= 16u) {
             for (int ch = ch_first; ch < nch; ch += 16) {
                 u32x4_t v[HW_ROWS / 16];
@@ -367,7 +360,6 @@ static __device__ __forceinline__ void resample_h_rows(const PackedJob &J, const
                 }
             }
         }
-#endif
     };
 #pragma unroll 1
     for (int rt = 0; rt < HW_ROWT; ++rt) {
@@ -391,13 +383,8 @@ static __device__ __forceinline__ void resample_h_rows(const PackedJob &J, const
         int sf[3] = {1 << (RS_BITS - 1), 1 << (RS_BITS - 1), 1 << (RS_BITS - 1)};
         int ss[3] = {1 << (RS_BITS - 1), 1 << (RS_BITS - 1), 1 << (RS_BITS - 1)};
         const int *rf = ktab + (size_t)cf * krow;
-#ifdef MDX_HW_NOTAPS
-        if (pair) hw_taps<true>(q, rf, ktab + (size_t)cs * krow - d, min(MDX_HW_NOTAPS, max(nf, d + ns)), sf, ss);
-        else hw_taps<false>(q, rf, rf, min(MDX_HW_NOTAPS, nf), sf, ss);
-#else
         if (pair) hw_taps<true>(q, rf, ktab + (size_t)cs * krow - d, max(nf, d + ns), sf, ss);
         else hw_taps<false>(q, rf, rf, nf, sf, ss);
-#endif
         const int xcf = cf - xo0, xcs = cs - xo0;
 #pragma unroll
         for (int c = 0; c < 3; ++c) s_out[(c * HW_ROWS + lane) * opitch + xcf] = clip8(sf[c]);
@@ -1004,14 +991,8 @@ MDX_EXPORT int mdx_resample_lanczos_u8(const mdx_resample_job *jobs, int njobs, 
     for (int i = 0; i < njobs; ++i)
         if (int rc = validate_resample(jobs[i])) return rc;
     hipStream_t st = (hipStream_t)stream;
-#ifdef MDX_DEV_SWITCHES      // A/B builds only (build.py MDX_BUILD_DEFINES=-DMDX_DEV_SWITCHES): the shipped library never reads the environment
-    const bool no_rows = getenv("MDX_RESAMPLE_NO_ROWS") != nullptr;
-    const int rows_budget = getenv("MDX_RESAMPLE_ROWS_LDS") ? atoi(getenv("MDX_RESAMPLE_ROWS_LDS")) : HW_LDS_BUDGET;
-    const int rows_cols_max = getenv("MDX_RESAMPLE_ROWS_COLS") ? atoi(getenv("MDX_RESAMPLE_ROWS_COLS")) : 64;
-#else
     const bool no_rows = false;
-    const int rows_budget = HW_LDS_BUDGET, rows_cols_max = 64;
-#endif
+    const int rows_budget = HW_LDS_BUDGET, rows_cols_max = 64;      // (swept in round 4: the comment at HW_LDS_BUDGET)
     // long filters first: their blocks run longest (95 taps for the 80-column scale of a KITTI frame), dispatched last they
     // are the launch's tail (measured: vertical pass of a batch 62 us in caller order)
     std::vector<int> order(njobs);

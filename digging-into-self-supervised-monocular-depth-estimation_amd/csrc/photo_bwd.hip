@@ -24,11 +24,9 @@ constexpr int NPIXB = (BX * BY + NT - 1) / NT;   // tile+2-halo pixels per threa
 // the same three planes, which keeps four blocks resident per CU instead of two.
 constexpr int ROWSB = TY / (NT / 64);   // output rows per thread (2)
 
+constexpr int BWD_WAVES = 3;            // waves per SIMD the register allocation is held to for S <= 3 (2 and 4 measured slower, round 3)
 template <int S, bool SAVED>
-#ifndef MDX_BWD_WAVES
-#define MDX_BWD_WAVES 3
-#endif
-__global__ __launch_bounds__(NT, S <= 3 ? MDX_BWD_WAVES : 1) void photometric_bwd_kernel(BwdArgs a)
+__global__ __launch_bounds__(NT, S <= 3 ? BWD_WAVES : 1) void photometric_bwd_kernel(BwdArgs a)
 {
     constexpr int N_T = 3 * BY * BX, N_X = S * 3 * BY * BX, N_ABG = 3 * FY * FX, N_SEL = (FY * FX + 3) / 4;
     constexpr int N_POOL = N_T + N_X + N_ABG + N_SEL, N_RED = S * 12 * NT;

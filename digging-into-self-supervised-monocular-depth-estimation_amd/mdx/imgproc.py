@@ -14,6 +14,7 @@ to Pillow's output divided by 255.
                                                                        (enabled, order[4], brightness, contrast,
                                                                         saturation, hue_shift)
 """
+import collections
 import ctypes as C
 
 import numpy as np
@@ -41,6 +42,9 @@ def _check_u8(t, what):
     _lib.ptr(t, torch.uint8)          # GPU, contiguous, uint8, on the CURRENT device (whose stream the library is given)
 
 
+Plan = collections.namedtuple("Plan", "ksize bounds kk bounds_ptr kk_ptr cols cols_ptr cols_lead cols_row")
+
+
 class plan_cache(object):
     """Lanczos plans (Resample.c precompute_coeffs) per (in_size, out_size): built on the host by the library, kept on
     the device.  KITTI raw has five image sizes, so a run holds ~40 small tables."""
@@ -49,9 +53,13 @@ class plan_cache(object):
         # cols = False withholds the column-major weight table: the horizontal pass then runs in its gather form (tests)
         self.device, self.plans, self.cols = device, {}, cols
 
-    def get(self, in_size, out_size):
+    def get(self, in_size, out_size, cols=False):
+        """-> Plan.  cols: the plan will serve the HORIZONTAL pass, whose rows form also reads the weights column-major
+        (mdx_resample_plan_cols: a second host pass over the plan and up to ~170 KB on the device) -- built on first request
+        only, a plan that only ever serves the vertical pass never pays for it."""
         key = (int(in_size), int(out_size))
-        if key not in self.plans:
+        plan = self.plans.get(key)
+        if plan is None:
             lib = _lib.lib()
             ksize = lib.mdx_resample_ksize(key[0], key[1])
             if ksize <= 0:
@@ -61,20 +69,23 @@ class plan_cache(object):
             _lib.check(lib.mdx_resample_plan(key[0], key[1], bounds.ctypes.data_as(C.c_void_p),
                                              kk.ctypes.data_as(C.c_void_p)), "mdx_resample_plan")
             tb, tk = torch.from_numpy(bounds).to(self.device), torch.from_numpy(kk).to(self.device)
+            # (device addresses kept beside the tensors: a batch asks for ~150 plans, data_ptr() is not free)
+            plan = self.plans[key] = Plan(ksize, tb, tk, tb.data_ptr(), tk.data_ptr(), None, 0, 0, 0)
+            # a plan outlives the call and may next be used from another stream (prefetcher / step): finish its upload now
+            torch.cuda.current_stream(self.device).synchronize()
+        if cols and self.cols and plan.cols is None:
             # the same weights column-major, zero-padded, both directions: what the rows form of the horizontal pass reads
             # with scalar loads (include/mdx.h, mdx_resample_plan_cols)
+            lib = _lib.lib()
             lead, row = C.c_int(0), C.c_int(0)
             _lib.check(lib.mdx_resample_plan_cols(key[0], key[1], C.byref(lead), C.byref(row), None), "mdx_resample_plan_cols")
             kc = np.zeros((2, key[1], row.value), np.int32)
             _lib.check(lib.mdx_resample_plan_cols(key[0], key[1], C.byref(lead), C.byref(row),
                                                   kc.ctypes.data_as(C.c_void_p)), "mdx_resample_plan_cols")
             tc = torch.from_numpy(kc).to(self.device)
-            # (ksize, bounds, kk, their device addresses, kc + its address and geometry): a batch asks for ~150 of these,
-            # data_ptr() is not free
-            self.plans[key] = (ksize, tb, tk, tb.data_ptr(), tk.data_ptr(), tc, tc.data_ptr() if self.cols else 0, lead.value, row.value)
-            # a plan outlives the call and may next be used from another stream (prefetcher / step): finish its upload now
+            plan = self.plans[key] = plan._replace(cols=tc, cols_ptr=tc.data_ptr(), cols_lead=lead.value, cols_row=row.value)
             torch.cuda.current_stream(self.device).synchronize()
-        return self.plans[key]
+        return plan
 
 
 def resize_lanczos_multi(plans, sources, sizes, flips, outs):
@@ -125,7 +136,7 @@ def resize_lanczos_multi(plans, sources, sizes, flips, outs):
                      u8.data_ptr() if want_u8 else 0, 3 * oh * ow if want_u8 else 0,
                      f32.data_ptr() if want_f32 else 0, 12 * oh * ow if want_f32 else 0, 3 * wmax, oh, ow))
         at += N * 3 * hmax * ow
-        xpl.append([plans.get(w, ow) for w in uw])
+        xpl.append([plans.get(w, ow, cols=True) for w in uw])
         ypl.append([plans.get(h, oh) for h in uh])
     c = np.array(cols, dtype=np.uint64)                                        # [O, 11]
     idx = np.arange(N, dtype=np.uint64)[None, :]
@@ -136,8 +147,9 @@ def resize_lanczos_multi(plans, sources, sizes, flips, outs):
     jobs["in_stride"], jobs["out_h"], jobs["out_w"] = c[:, 8:9], c[:, 9:10], c[:, 10:11]
     jobs["in_h"], jobs["in_w"] = np.array(hl, np.int32)[None, :], np.array(wl, np.int32)[None, :]
     jobs["flip"] = np.array([int(bool(f)) for f in flips], np.int32)[None, :]
-    xa = np.array([[(p[3], p[4], p[0], p[6], p[7], p[8]) for p in row] for row in xpl], dtype=np.uint64)[:, winv]     # [O, N, 6]
-    ya = np.array([[(p[3], p[4], p[0]) for p in row] for row in ypl], dtype=np.uint64)[:, hinv]
+    xa = np.array([[(p.bounds_ptr, p.kk_ptr, p.ksize, p.cols_ptr, p.cols_lead, p.cols_row) for p in row] for row in xpl],
+                  dtype=np.uint64)[:, winv]                                                                         # [O, N, 6]
+    ya = np.array([[(p.bounds_ptr, p.kk_ptr, p.ksize) for p in row] for row in ypl], dtype=np.uint64)[:, hinv]
     jobs["xbounds"], jobs["xkk"], jobs["xksize"] = xa[:, :, 0], xa[:, :, 1], xa[:, :, 2]
     jobs["xkc"], jobs["xkc_lead"], jobs["xkc_row"] = xa[:, :, 3], xa[:, :, 4], xa[:, :, 5]
     jobs["ybounds"], jobs["ykk"], jobs["yksize"] = ya[:, :, 0], ya[:, :, 1], ya[:, :, 2]

@@ -82,9 +82,11 @@ def collate_raw(samples, keep=None):
                            for s in samples])
         rest[("depth_idx", 0)], rest[("depth_val", 0)] = idx, val
     if raw_keys:
-        hmax = max(int(s[raw_keys[0]].shape[0]) for s in samples)
-        wmax = max(int(s[raw_keys[0]].shape[1]) for s in samples)
-        ragged_frames = any(tuple(s[raw_keys[0]].shape[:2]) != (hmax, wmax) for s in samples)
+        # over EVERY raw key: the frames of a sample share one size today, but a key whose frames differ (another camera) must
+        # not be left with uninitialised padding because the first key happened to be uniform
+        hmax = max(int(s[k].shape[0]) for s in samples for k in raw_keys)
+        wmax = max(int(s[k].shape[1]) for s in samples for k in raw_keys)
+        ragged_frames = any(tuple(s[k].shape[:2]) != (hmax, wmax) for s in samples for k in raw_keys)
         for k in raw_keys:
             # 16.8 MB per frame id at batch 12: allocated IN shared memory when this runs in a DataLoader worker (what
             # default_collate does for its stacks) -- a block built in private memory is copied into shared memory when the
@@ -107,8 +109,11 @@ def _batch_block(shape, dtype):
     for v in shape:
         numel *= int(v)
     elem = torch.empty(0, dtype=dtype)
-    storage = elem._typed_storage()._new_shared(numel, device=elem.device)
-    return elem.new(storage).resize_(*shape)
+    try:            # what default_collate does for its stacks (private torch API: guarded, the public path below is merely slower)
+        storage = elem._typed_storage()._new_shared(numel, device=elem.device)
+        return elem.new(storage).resize_(*shape)
+    except (AttributeError, TypeError, RuntimeError):
+        return torch.zeros(shape, dtype=dtype).share_memory_()
 
 
 class KITTIDataset(Dataset):

@@ -239,6 +239,13 @@ class trainer(object):
         into a hipGraph and replayed (graphed_step); otherwise eager."""
         use_graph = getattr(self.opt, "graph", False) and self.can_graph()
         if not use_graph:
+            if getattr(self.opt, "graph", False) and not getattr(self, "_told_eager", False) and str(self.device).startswith("cuda"):
+                self._told_eager = True       # once, rank 0: --graph was asked for and the step runs eager (other bucket sizes, queues)
+                if self.rank == 0:
+                    why = ("--noise cpu draws on the host" if self.compute.noise_mode == "cpu" else
+                           "several ranks: the captured data-parallel step is opt-in, set MDX_DP_GRAPH=1 (model_tool/parallel.py: "
+                           "dp_graph_allowed) -- or the process group is not RCCL")
+                    print("model_train: --graph requested but the step is not captured (%s); running the eager step" % why, flush=True)
             return self._eager_step(inputs)
         inputs = self.compute.prepare(inputs)     # decoded frames -> step entries (a no-op after the prefetcher)
         if self._graphed is None:

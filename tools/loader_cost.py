@@ -180,10 +180,10 @@ def rank_child(root, k, workers, batch, seconds, pin, height, width, frames=(0, 
     os._exit(0)                                    # do not wait for the workers' queues to drain
 
 
-def rehearse(ranks, workers, batch, seconds, pin, height, width, need=1.3 * 900.0):
+def rehearse(ranks, workers, batch, seconds, pin, height, width, need=1.3 * 1130.0):
     """VERDICT r3 missing #3: can ONE host feed `ranks` GPUs?  `ranks` independent DataLoader sets, `workers` worker
     processes each, started together on this box's cores; per-set and aggregate samples/s against what a bf16 rank
-    consumes (~900 samples/s, target 1.3x)."""
+    consumes (~1130 samples/s with channels-last bf16 networks, round 5; target 1.3x: --consume changes it)."""
     import subprocess
     import fake_kitti
     out = {"ranks": ranks, "workers_per_rank": workers, "batch": batch, "pinned": bool(pin), "seconds": seconds,
@@ -220,7 +220,10 @@ def rehearse(ranks, workers, batch, seconds, pin, height, width, need=1.3 * 900.
             res.append(json.loads(lines[-1]) if lines else {"error": se.decode()[-300:]})
     rates = [r.get("samples_per_s", 0.0) for r in res]
     out.update({"per_rank_samples_per_s": rates, "aggregate_samples_per_s": round(sum(rates), 1), "min_rank": min(rates),
-                "every_rank_meets_need": bool(min(rates) >= need)})
+                "every_rank_meets_need": bool(min(rates) >= need),
+                "verdict": ("PASS: every set delivers >= %.0f samples/s" % need) if min(rates) >= need else
+                           ("FAIL: the slowest set delivers %.0f of the %.0f samples/s a rank needs (1.3 x consumption): raise --workers, "
+                            "or give every rank more cores" % (min(rates), need))})
     return out
 
 
@@ -234,6 +237,7 @@ def main():
     ap.add_argument("--workers", type=int, default=0, help="also time the DataLoader with this many worker processes")
     ap.add_argument("--ranks", type=int, default=0, help="host-feed rehearsal: this many independent DataLoader sets side by side")
     ap.add_argument("--seconds", type=float, default=12.0)
+    ap.add_argument("--consume", type=float, default=1130.0, help="rehearsal: samples/s one rank's step consumes (the bar is 1.3 x this)")
     ap.add_argument("--pin", type=int, default=0, help="rehearsal: pinned batches (initialises the GPU in every set: at most 6 on a gpurun box)")
     ap.add_argument("--rank-child", type=int, default=-1, help=argparse.SUPPRESS)
     ap.add_argument("--root", type=str, default="", help=argparse.SUPPRESS)
@@ -241,7 +245,9 @@ def main():
     if a.rank_child >= 0:
         return rank_child(a.root, a.rank_child, a.workers, a.batch, a.seconds, a.pin, a.height, a.width)
     if a.ranks > 0:
-        print(json.dumps(rehearse(a.ranks, a.workers or 16, a.batch, a.seconds, a.pin, a.height, a.width)))
+        res = rehearse(a.ranks, a.workers or 24, a.batch, a.seconds, a.pin, a.height, a.width, need=1.3 * a.consume)
+        print(json.dumps(res))
+        sys.stderr.write(res.get("verdict", res.get("error", "")) + "\n")
         return
     print(json.dumps(measure(a.samples, a.batch, a.reps, a.height, a.width, workers=a.workers)))
 
