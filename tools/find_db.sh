@@ -7,7 +7,7 @@ ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 TAG="${1:-nhwc}"; shift
 PKG="$ROOT/digging-into-self-supervised-monocular-depth-estimation_amd"
 DB="$ROOT/gpurun_out/miopen_db_$TAG"; OUT="$ROOT/gpurun_out/find_$TAG"; mkdir -p "$DB" "$OUT"; cd "$ROOT"
-[ -n "$(ls "$DB" 2>/dev/null)" ] || cp "$PKG"/miopen_db/*.txt "$DB"/
+[ -n "$(ls "$DB" 2>/dev/null)" ] || { cp "$PKG"/miopen_db/*.txt "$DB"/; mkdir -p "$DB/base"; cp "$PKG"/miopen_db/*.txt "$DB/base"/; }
 export MIOPEN_USER_DB_PATH="$DB"
 B="--no-cpu-baseline --no-trainer-loop --no-roofline"
 ( while sleep 45; do echo "[find] $(date +%T) db lines: $(cat "$DB"/*.ufdb.txt | wc -l)"; done ) & TICK=$!

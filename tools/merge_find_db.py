@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Merge the lines MIOpen appended to a recorded user db (gpurun_out/miopen_db_<tag>/) into the shipped one
 (digging-into-self-supervised-monocular-depth-estimation_amd/miopen_db/): per file, a line replaces the shipped line with the
-same key (the text before '='), new keys are appended.  Prints what changed.
+same key (the text before '='), new keys are appended.  Only lines the recording itself changed are taken: tools/find_db.sh keeps
+the files it started from under <dir>/base/, and a line equal to its base line is left alone (two recordings started from the same
+shipped db would otherwise undo each other's results when merged one after the other).  Prints what changed.
 
     python tools/merge_find_db.py gpurun_out/miopen_db_nhwc_fp32 [more directories]
 """
@@ -28,6 +30,8 @@ def main():
             if not name.endswith(".txt"):
                 continue
             have, new = read(os.path.join(DST, name)), read(os.path.join(src, name))
+            base = read(os.path.join(src, "base", name))
+            new = {k: v for k, v in new.items() if base.get(k) != v}
             added = [k for k in new if k not in have]
             changed = [k for k in new if k in have and have[k] != new[k]]
             have.update(new)
