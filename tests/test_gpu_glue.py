@@ -266,7 +266,17 @@ def test_encoder_fused_norm_path_equals_module_path(layers, cl, monkeypatch):
         enc = enc.to(memory_format=torch.channels_last)
     # 128x256: every map's H*W is a multiple of 4 (MIOpen's batch norm, the reference here, is off for other planes)
     img = torch.rand(4, 3, 128, 256, device="cuda")
+    # no map changes its layout inside a network whose stages share one (ResNet-50's layers begin with a 1x1 convolution, whose
+    # weight is planar and channels-last at once: read as planar it sent every layer's input through a transposing copy)
+    import mdx.layout as L
+    made = []
+    real = torch.Tensor.contiguous
+    monkeypatch.setattr(torch.Tensor, "contiguous", lambda t, *a, **k: (made.append(tuple(t.shape)) if t.dim() == 4 and t.shape[1] > 3 and not (
+        t.is_contiguous(memory_format=k.get("memory_format", torch.contiguous_format))) else None, real(t, *a, **k))[1])
     feats = enc(img)
+    monkeypatch.setattr(torch.Tensor, "contiguous", real)
+    assert not made, "layout-changing copies of feature maps: %s" % made
+    assert all(L.weight_layout(getattr(enc.encoder, "layer%d" % i)) == cl for i in (1, 2, 3, 4))
     if cl:
         assert all(f.is_contiguous(memory_format=torch.channels_last) for f in feats)
     loss = sum(f.mean() for f in feats)

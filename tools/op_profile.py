@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Which ATen ops (not kernels) does a step spend its GPU time in, with their input shapes?  torch.profiler over a few eager steps
+of bench.py's trainer -- what rocprofv3's kernel names cannot say (e.g. which call makes a strided layout-changing copy).
+
+    python tools/op_profile.py [--num-layers 50 --height 320 --width 1024 --batch 8 --amp bf16] [--top 40]
+"""
+import argparse
+import importlib
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("digging-into-self-supervised-monocular-depth-estimation_amd")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=12)
+    ap.add_argument("--height", type=int, default=192)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--num-layers", type=int, default=18)
+    ap.add_argument("--amp", default="none")
+    ap.add_argument("--channels-last", default="auto")
+    ap.add_argument("--top", type=int, default=40)
+    ap.add_argument("--filter", default="", help="only ops whose name contains this (e.g. copy_)")
+    a = ap.parse_args()
+    bench = importlib.import_module("bench")
+    from model_train import trainer
+    pkg.install_miopen_db(0)
+    opt = bench.make_opt(a.batch, height=a.height, width=a.width, num_layers=a.num_layers, amp=a.amp)
+    opt.channels_last, opt.graph, opt.miopen_find, opt.max_steps = a.channels_last, False, False, 0
+    tr = trainer(opt)
+    tr.setting.set_train()
+    inputs = bench.one_batch(tr.setting, tr.device)
+    for _ in range(3):
+        tr._eager_step(inputs)
+    torch.cuda.synchronize()
+    from torch.profiler import ProfilerActivity, profile
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+        for _ in range(2):
+            tr._eager_step(inputs)
+        torch.cuda.synchronize()
+    rows = []
+    for e in prof.key_averages(group_by_input_shape=True):
+        t = getattr(e, "self_device_time_total", None)
+        if t is None:
+            t = getattr(e, "self_cuda_time_total", 0)
+        if t > 0 and a.filter in e.key:
+            rows.append((t / 2e3, e.count // 2, e.key, str(e.input_shapes)[:150]))
+    rows.sort(reverse=True)
+    print("%9s %6s  %-44s %s" % ("ms/step", "calls", "op", "input shapes"))
+    for t, n, k, s in rows[:a.top]:
+        print("%9.3f %6d  %-44s %s" % (t, n, k[:44], s))
+
+
+if __name__ == "__main__":
+    main()
