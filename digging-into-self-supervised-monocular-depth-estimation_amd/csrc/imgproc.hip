@@ -284,7 +284,7 @@ static __device__ __forceinline__ void resample_h_rows(const PackedJob &J, const
     const int nch = min((3 * px_hi + 3 - a0 + 15) >> 4, (pitch - 12) >> 4);
     // readable bytes of the image: the LAST row ends at 3 * in_w, not at in_stride (a bottom-right crop view of a larger image has
     // nothing behind it; the chunk that straddles the end is repaired by the shift below)
-    const unsigned total = (unsigned)(in_h - 1) * (unsigned)J.in_stride + 3u * (unsigned)J.in_w;
+    const unsigned total = (unsigned)(in_h - 1) * (unsigned)J.in_stride + 3u * (unsigned)X.in_w;
     // Every global load of the set-up is issued before the first LDS write that depends on one.  The first form staged chunk by
     // chunk -- `if (inside) 16-byte load else byte-wise tail`, then the LDS write, per pass of a 4 x (1..4)-pass loop nest -- and
     // the compiler put s_waitcnt vmcnt(0) behind each load: 4 to 16 memory round trips in a row per block

@@ -40,8 +40,17 @@ static inline Rows make_rows(long long M, int C, int N, int max_blocks, int min_
     g.nblk = (int)((M + RB - 1) / RB);
     return g;
 }
-constexpr int STATS_MAX_BLOCKS = 512;     // partials per channel the finalize pass sums (x 2 values x 4 bytes)
+// Blocks along the rows.  The statistics passes want FEW blocks: every block leaves one partial per channel and the finalize
+// pass that adds them is a chain of fabric round trips (tools/ab_netbench.sh over the maps of BASELINE configs[1] and [3], sum of
+// the forward / backward times: 1024 blocks 447 / 789 us, 512: 377 / 702, 256: 352 / 663, 128: 350 / 694 in float32; the
+// bfloat16 backward, three 2-byte streams per row, is the one that still gains from more blocks: 256: 1463 us, 384: 1407, 512:
+// 1424).  The apply passes stream and take many.
+constexpr int STATS_FWD_BLOCKS = 256;
+constexpr int STATS_BWD_BLOCKS_F32 = 256, STATS_BWD_BLOCKS_BF16 = 384;
+constexpr int STATS_MAX_BLOCKS = 384;      // the largest of the three: sizes the workspace and the finalize pass's unrolled loads
 constexpr int APPLY_MAX_BLOCKS = 4096;
+constexpr int STATS_ITERS = 8, APPLY_ITERS = 4;          // row sweeps a block is given at least (small maps: fewer blocks)
+static inline int stats_bwd_blocks(int dtype) { return dtype == 0 ? STATS_BWD_BLOCKS_F32 : STATS_BWD_BLOCKS_BF16; }
 
 struct Pos { int cv, pl, r0, r1, g; bool active; };
 template <int N> __device__ __forceinline__ Pos position(int M, int C, int CVB, int PL, int RB)
@@ -117,7 +126,7 @@ __global__ __launch_bounds__(NB) void bn_nhwc_fwd_stats_kernel(const T *__restri
 }
 
 // ---- partials -> per-channel totals: a block = 16 channels x 64 sub-sums (1024 threads), float64 -------------------
-// Every thread has at most 8 partials to add (STATS_MAX_BLOCKS / FS): all 16 loads are issued before the first add -- the
+// Every thread has at most FU = STATS_MAX_BLOCKS / FS partials to add: all 2 FU loads are issued before the first add -- the
 // partials were written a moment ago by blocks on all eight XCDs, each load is a trip through the fabric, and a loop with
 // one load per iteration made this pass (4 blocks for a 64-channel map) the longest of the three.
 constexpr int FC = 16, FS = 64, FU = STATS_MAX_BLOCKS / FS;
@@ -383,7 +392,7 @@ using namespace mdx::nhwc;
 MDX_EXPORT size_t mdx_bn_nhwc_workspace_bytes(int B, int C, int H, int W, int groups, int dtype)
 {
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || groups <= 0 || (dtype != 0 && dtype != 1)) return 0;
-    const Rows g = make_rows((long long)B * H * W, C, vec_elems(dtype), STATS_MAX_BLOCKS, 8);
+    const Rows g = make_rows((long long)B * H * W, C, vec_elems(dtype), STATS_MAX_BLOCKS, STATS_ITERS);
     return ((size_t)groups * g.nblk * 2 * C + (size_t)groups * 2 * C) * sizeof(float);
 }
 
@@ -410,7 +419,7 @@ MDX_EXPORT int mdx_bn_act_nhwc_fwd(const void *x, const void *res, const float *
     if (!aligned(x, 16) || !aligned(y, 16) || (res && !aligned(res, 16))) return MDX_ERR_MISALIGNED;
     if (workspace_bytes < mdx_bn_nhwc_workspace_bytes(B, C, H, W, groups, dtype)) return MDX_ERR_WORKSPACE;
     const int M = B * H * W, N = vec_elems(dtype);
-    const Rows gs = make_rows(M, C, N, STATS_MAX_BLOCKS, 8), ga = make_rows(M, C, N, APPLY_MAX_BLOCKS, 4);
+    const Rows gs = make_rows(M, C, N, STATS_FWD_BLOCKS, STATS_ITERS), ga = make_rows(M, C, N, APPLY_MAX_BLOCKS, APPLY_ITERS);
     float *part = (float *)workspace;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid_s(gs.nblk, gs.t.ny, groups), grid_a(ga.nblk, ga.t.ny, groups), block(NB);
@@ -444,7 +453,7 @@ MDX_EXPORT int mdx_bn_act_nhwc_bwd(const void *dy, const void *dy2, const void *
         return MDX_ERR_MISALIGNED;
     if (workspace_bytes < mdx_bn_nhwc_workspace_bytes(B, C, H, W, groups, dtype)) return MDX_ERR_WORKSPACE;
     const int M = B * H * W, N = vec_elems(dtype);
-    const Rows gs = make_rows(M, C, N, STATS_MAX_BLOCKS, 8), ga = make_rows(M, C, N, APPLY_MAX_BLOCKS, 4);
+    const Rows gs = make_rows(M, C, N, stats_bwd_blocks(dtype), STATS_ITERS), ga = make_rows(M, C, N, APPLY_MAX_BLOCKS, APPLY_ITERS);
     float *part = (float *)workspace;
     float *totals = part + (size_t)groups * gs.nblk * 2 * C;
     hipStream_t st = (hipStream_t)stream;

@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--bf16", action="store_true")
     ap.add_argument("--config", type=int, default=1, choices=[1, 3])
     ap.add_argument("--json", type=str, default="")
+    ap.add_argument("--only", type=str, default="", help="bn | glue | pool: only this family")
     a = ap.parse_args()
     dt = torch.bfloat16 if a.bf16 else torch.float32
     if a.config == 1:       # ResNet-18, 192x640, batch 12 (depth) / 2 x 12 (both pose pairs in one batch)
@@ -123,7 +124,7 @@ def main():
             bn_shapes += [(B, c // 4, hh, ww, False, 1)]
     rows = []
     print("%-46s %21s %21s" % ("op / shape", "planar fwd | bwd us (GB/s)", "channels-last fwd | bwd us (GB/s)"))
-    for (b, c, hh, ww, res, g) in bn_shapes:
+    for (b, c, hh, ww, res, g) in (bn_shapes if a.only in ("", "bn") else []):
         r = {}
         for cl in (False, True):
             r[cl] = bn_case(b, c, hh, ww, res, g, dt, cl)
@@ -135,12 +136,12 @@ def main():
         hh, ww = H0 // (2 << i), W0 // (2 << i)
         glue_shapes += [(B, dec[i], ch[i - 1] if i > 0 else 0, hh, ww, True, True)]
         glue_shapes += [(B, dec[i], 0, 2 * hh, 2 * ww, False, True)]
-    for (b, c1, c2, hh, ww, up, elu) in glue_shapes:
+    for (b, c1, c2, hh, ww, up, elu) in (glue_shapes if a.only in ("", "glue") else []):
         r = {}
         for cl in (False, True):
             r[cl] = glue_case(b, c1, c2, hh, ww, up, elu, dt, cl)
         rows.append(("decoder_glue B=%d C1=%d C2=%d %dx%d up=%d" % (b, c1, c2, hh, ww, up), r))
-    for b in (B, 2 * B):
+    for b in ((B, 2 * B) if a.only in ("", "pool") else ()):
         r = {}
         for cl in (False, True):
             r[cl] = pool_case(b, 64, H0 // 2, W0 // 2, dt, cl)
