@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MDX_VERSION 401
+#define MDX_VERSION 500
 #define MDX_MAX_SRC 4
 #define MDX_MAX_SCALES 4
 

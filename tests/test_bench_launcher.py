@@ -46,7 +46,7 @@ def test_self_launch_two_ranks_gloo():
 
 
 def test_committed_counter_summary_matches_the_sources():
-    """bench.py quotes profiles/r04_bench_kernel_pmc.json, r04_pmc_c4.json, r04_pmc_c3.json (traffic, vector-ALU busy time) only
+    """bench.py quotes profiles/r05_bench_kernel_pmc.json, r05_pmc_c4.json, r05_pmc_c3.json (traffic, vector-ALU busy time) only
     for the build they were taken on, recognised by the hash of the kernel sources and flags, and for their workload shape.  The
     three files must come from ONE build; a source change without a new counter pass makes those fields null in the bench line:
     this test says so (skip, not failure: the numbers' absence is reported by bench.py itself)."""
@@ -59,7 +59,7 @@ def test_committed_counter_summary_matches_the_sources():
     b = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(b)
     assert len(b.source_sha16()) == 16
-    shapes = {"r04_bench_kernel_pmc.json": [12, 192, 640, 2, 4], "r04_pmc_c4.json": [12, 192, 640, 3, 4], "r04_pmc_c3.json": [8, 320, 1024, 2, 4]}
+    shapes = {"r05_bench_kernel_pmc.json": [12, 192, 640, 2, 4], "r05_pmc_c4.json": [12, 192, 640, 3, 4], "r05_pmc_c3.json": [8, 320, 1024, 2, 4]}
     pmcs = {n: json.load(open(os.path.join(root, "profiles", n))) for n in shapes}
     assert all(pmcs[n]["shape"] == shapes[n] for n in shapes)
     assert len({p["source_sha16"] for p in pmcs.values()}) == 1, "the three counter files come from different builds"
@@ -67,5 +67,5 @@ def test_committed_counter_summary_matches_the_sources():
         assert any("photometric_train_kernel" in k and "valu_busy_us" in v for k, v in p["kernels"].items()), n
     have = next(iter(pmcs.values()))["source_sha16"]
     if have != b.source_sha16():
-        pytest.skip("profiles/r04_*pmc*.json were taken on other kernel sources (%s, now %s): run tools/r4_pmc_configs.sh on the "
+        pytest.skip("profiles/r05_*pmc*.json were taken on other kernel sources (%s, now %s): run tools/pmc_configs.sh train on the "
                     "GPU box and tools/pmc_to_json.py" % (have, b.source_sha16()))

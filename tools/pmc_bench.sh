@@ -2,7 +2,9 @@
 # PMC + kernel-trace passes over bench.py ITSELF: the counters of the photometric kernels are taken on the launches
 # (and tensors) of the very step bench.py times -- VERDICT r2 weak #2: round 2's counters came from tools/kbench.py's data.
 #   gpurun --timeout 1100 -- '[PMC_OUT=dir PMC_SHAPE="B=.., HxW, S=.."] bash tools/pmc_bench.sh [extra bench.py args]'
-#   python tools/pmc_to_json.py gpurun_out/pmc_bench profiles/r03_bench_kernel_pmc.json 12 192 640 2 4
+#   python tools/pmc_to_json.py gpurun_out/pmc_bench profiles/r05_bench_kernel_pmc.json 12 192 640 2 4
+# PMC_NET=1: the network kernels between the convolutions instead (batch norm, decoder glue, max-pool; three passes: FETCH_SIZE,
+# WRITE_SIZE, activity), summarised per kernel AND launch geometry by tools/pmc_net.py (their maps differ from layer to layer)
 # rocprofv3 rules on this pool: program directly after `--`, counters in their own passes (only --kernel-trace beside
 # --pmc), cwd /tmp.  --kernel-include-regex keeps the serialising counter collection off the ~1600 other launches of a step.
 set -o pipefail
@@ -13,13 +15,19 @@ BENCH="$ROOT/bench.py --no-cpu-baseline --no-trainer-loop --no-roofline"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 $BENCH --steps 30 --warmup 10 "$@" > "$OUT/trace.log" 2>&1
 echo "trace rc=$?"
 i=0
-for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" \
+REGEX="mdx::(photometric|train_finish|smooth)"
+GROUPS_ALL=("SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" \
            "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
            "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_RD" \
            "SQ_INST_CYCLES_VMEM_RD SQ_INSTS_VMEM_WR SQ_IFETCH SQ_WAIT_INST_LDS" \
-           "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"; do
+           "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum")
+if [ -n "$PMC_NET" ]; then
+    REGEX="mdx::(nhwc::|bn_|decoder_glue|maxpool)"
+    GROUPS_ALL=("FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY")
+fi
+for grp in "${GROUPS_ALL[@]}"; do
     i=$((i + 1))
-    timeout -k 10 200 rocprofv3 --kernel-trace --pmc $grp --kernel-include-regex "mdx::(photometric|train_finish|smooth)" \
+    timeout -k 10 200 rocprofv3 --kernel-trace --pmc $grp --kernel-include-regex "$REGEX" \
         --output-format csv -d "$OUT/pmc_$i" -- python3 $BENCH --steps 6 --warmup 4 "$@" > "$OUT/pmc_$i.log" 2>&1
     echo "pmc pass $i ($grp): rc=$?"
 done
@@ -28,5 +36,9 @@ done
 find "$OUT" -name '*_kernel_trace.csv' | while read -r f; do { head -1 "$f"; grep 'mdx::' "$f"; } > "$f.tmp"; mv "$f.tmp" "$f"; done
 find "$OUT" \( -name '*.db' -o -name '*.pftrace' -o -name '*.json' \) -size +1M -delete
 du -sh "$OUT" | sed 's/^/kept: /'
-MDX_PMC_TITLE="python bench.py $*: the timed step's own launches; ${PMC_SHAPE:-B=12, 192x640, S=2}, four scales" MDX_PMC_FILTER="mdx::photometric,mdx::train_finish,mdx::smooth" python3 "$ROOT/tools/pmc_summary.py" "$OUT/summary.txt" "$OUT"/pmc_* > /dev/null
-cat "$OUT/summary.txt"
+if [ -n "$PMC_NET" ]; then
+    python3 "$ROOT/tools/pmc_net.py" "$OUT" "$OUT/summary.txt" "python bench.py $*: the step's own launches of the network kernels; ${PMC_SHAPE:-B=12, 192x640}"
+else
+    MDX_PMC_TITLE="python bench.py $*: the timed step's own launches; ${PMC_SHAPE:-B=12, 192x640, S=2}, four scales" MDX_PMC_FILTER="mdx::photometric,mdx::train_finish,mdx::smooth" python3 "$ROOT/tools/pmc_summary.py" "$OUT/summary.txt" "$OUT"/pmc_* > /dev/null
+    cat "$OUT/summary.txt"
+fi
