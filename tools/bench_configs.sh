@@ -1,7 +1,7 @@
 #!/bin/bash
-# BASELINE.json configs[2..4] on ONE GPU (their 8-GPU form is the driver's to run): bench lines under gpurun_out/configs_r4/
+# BASELINE.json configs[2..4] on ONE GPU (their 8-GPU form is the driver's to run): bench lines under gpurun_out/configs_r5/
 ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
-OUT="$ROOT/gpurun_out/configs_r4"; mkdir -p "$OUT"; cd "$ROOT"
+OUT="$ROOT/gpurun_out/configs_r5"; mkdir -p "$OUT"; cd "$ROOT"
 run() { n=$1; shift; timeout -k 10 500 python bench.py --no-cpu-baseline --no-trainer-loop --steps 40 --warmup 10 "$@" > "$OUT/$n.json" 2> "$OUT/$n.err" || { echo "$n FAILED"; tail -3 "$OUT/$n.err"; return; }
 python - "$OUT/$n.json" "$n" <<'PY'
 import json,sys
