@@ -405,6 +405,7 @@ def trainer_loop(args, frame_ids, steps, warmup, workers, raw):
     opt.fused_train = not args.per_scale_kernels
     opt.grad_comm, opt.bucket_mb = args.grad_comm, args.bucket_mb
     opt.channels_last = args.channels_last
+    opt.overlap_pose = not args.no_overlap_pose
     world = int(os.environ.get("WORLD_SIZE", "1"))
     opt.synthetic_length = (steps + warmup + 4) * args.batch * world
     opt.synthetic_pool = 4 * args.batch          # the stand-in dataset must not be what is measured
@@ -526,6 +527,8 @@ def main():
     ap.add_argument("--workers", type=int, default=0,
                     help="DataLoader workers of the trainer-loop measurement (0 = sized from the host share of this rank: "
                          "12 for fp32, up to 24 with --amp bf16 whose step consumes ~900 samples/s)")
+    ap.add_argument("--no-overlap-pose", action="store_true",
+                    help="pose network AFTER the depth network instead of beside it on a side stream (A/B: model_option --overlap_pose 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--selftest-launcher", action="store_true", help=argparse.SUPPRESS)
@@ -590,6 +593,7 @@ def main():
     opt = make_opt(args.batch, height=args.height, width=args.width, frame_ids=frame_ids, num_layers=args.num_layers,
                    amp=args.amp)
     opt.channels_last = args.channels_last
+    opt.overlap_pose = not args.no_overlap_pose
     opt.fused_train = not args.per_scale_kernels
     opt.grad_comm, opt.bucket_mb = args.grad_comm, args.bucket_mb
     opt.prologue = not args.no_prologue
@@ -684,6 +688,7 @@ def main():
             "ranks_verified": ranks_verified, "final_loss": loss_val, "hip_graph": bool(graph is not None), "miopen_find_db": bool(miopen_db),
             "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms), "argmax_rank": int(max(range(len(rank_ms)), key=rank_ms.__getitem__))},
             "channels_last": sorted(getattr(st, "channels_last_stages", ())),
+            "pose_beside_depth": bool(tr._pose_beside_depth()),
         }
         if st.sync is not None:
             line["gradient_exchange"] = {"backend": "rccl" if st.sync.backend == "nccl" else st.sync.backend,

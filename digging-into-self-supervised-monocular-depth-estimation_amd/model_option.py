@@ -54,6 +54,9 @@ def options(argv=None):
                    help="synthetic dataset hands over KITTI-sized decoded frames (1242x375 uint8), as the KITTI loaders do with gpu_image_prep")
     p.add_argument("--resume", type=int, default=0,
                    help="restart after this many finished epochs from ./model_save/<save>/ (weights <key><N>.pt + state<N>.pt)")
+    p.add_argument("--overlap_pose", type=int, default=1,
+                   help="1: the separate pose network runs on a side stream beside the depth network, forward and backward (many of "
+                        "their kernels are too small to fill the GPU alone: +13 %% fp32, +32 %% bf16 on one MI355X); 0: one after the other")
     p.add_argument("--synthetic_geometry", action="store_true",
                    help="synthetic dataset: frames rendered from one rigid textured scene at known poses, ground truth = its "
                         "depth (model_tool/synthetic.py: scene) -- for tests of what the step learns")

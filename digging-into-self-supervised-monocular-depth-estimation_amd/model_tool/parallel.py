@@ -135,8 +135,14 @@ class grad_sync(object):
     def _reset(self):
         self._pending = [len(m) for _, _, m in self.buckets]
         self._next = 0                     # buckets are issued strictly in order: every rank issues the same sequence
+        self._streams = []                 # streams that have produced gradients since zero() (the pose network's backward runs
+                                           # beside the depth network's on a side stream: model_train.trainer.batch_process)
 
     def _ready(self, p):
+        if p.is_cuda:
+            cur = torch.cuda.current_stream(p.device)
+            if all(cur != t for t in self._streams):
+                self._streams.append(cur)
         k = self._bucket_of[id(p)]
         if k < self._next:
             # the bucket is on the wire (or back) and `.grad` is the exchanged view: this gradient comes from a SECOND
@@ -150,6 +156,13 @@ class grad_sync(object):
 
     def _issue(self, k):
         a, b, members = self.buckets[k]
+        if self.flat.is_cuda:
+            # a bucket may hold gradients written on another stream than the one that issues it: order this stream behind all
+            # of them (a stream-side wait; capturable)
+            cur = torch.cuda.current_stream(self.flat.device)
+            for t in self._streams:
+                if t != cur:
+                    cur.wait_stream(t)
         dst, src = [], []
         for p in members:
             v = self._views[id(p)]

@@ -94,7 +94,9 @@ class compute(object):
         inputs.update(prepared)
         return inputs
 
-    def forward_depth(self, inputs, outputs, setting):
+    def stage_inputs(self, inputs):
+        """What forward_depth does to the batch before the networks run (decoded frames -> step entries, upload, uint8 -> float32):
+        idempotent, so a caller that wants the pose network to start beside the depth network calls it first."""
         dev = torch.device(self.device)
         inputs = self.prepare(inputs)
         for key in inputs:
@@ -109,6 +111,10 @@ class compute(object):
                     inputs[key] = to_tensor(inputs[key])
                 else:
                     inputs[key] = torch.true_divide(inputs[key], 255.0)      # ATen's CPU kernel divides
+        return inputs
+
+    def forward_depth(self, inputs, outputs, setting):
+        inputs = self.stage_inputs(inputs)
         with self._autocast():
             if self.opt.pose_type == "shared":
                 all_frames = torch.cat([inputs[("color_aug", f, 0)] for f in self.opt.frame_ids])

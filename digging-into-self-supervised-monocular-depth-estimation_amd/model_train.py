@@ -197,6 +197,12 @@ class trainer(object):
         self.compute = compute(opt, self.device)
         self.control = control(opt, self.device)
 
+    _pose_stream = None
+
+    def _pose_beside_depth(self):
+        return (bool(getattr(self.opt, "overlap_pose", True)) and str(self.device).startswith("cuda")
+                and self.opt.pose_type in ("separate", "posecnn") and torch.is_grad_enabled())
+
     def batches(self, loader):
         """The loader's batches, uploaded one step ahead on a side stream (GPU) or as they are (CPU)."""
         if str(self.device).startswith("cuda") and getattr(self.opt, "device_prefetch", True):
@@ -205,8 +211,22 @@ class trainer(object):
 
     def batch_process(self, inputs):
         outputs = {}
-        inputs, outputs = self.compute.forward_depth(inputs, outputs, self.setting)
-        inputs, outputs = self.compute.forward_pose(inputs, outputs, self.setting)
+        if self._pose_beside_depth():
+            # the separate pose network does not depend on the depth network: it runs on a side stream beside it (forward here,
+            # backward likewise -- autograd runs a node's backward on its forward's stream); many of both networks' kernels are
+            # too small to fill the GPU on their own
+            inputs = self.compute.stage_inputs(inputs)
+            cur = torch.cuda.current_stream(self.device)
+            if self._pose_stream is None:
+                self._pose_stream = torch.cuda.Stream(self.device)
+            self._pose_stream.wait_stream(cur)
+            with torch.cuda.stream(self._pose_stream):
+                inputs, outputs = self.compute.forward_pose(inputs, outputs, self.setting)
+            inputs, outputs = self.compute.forward_depth(inputs, outputs, self.setting)
+            cur.wait_stream(self._pose_stream)
+        else:
+            inputs, outputs = self.compute.forward_depth(inputs, outputs, self.setting)
+            inputs, outputs = self.compute.forward_pose(inputs, outputs, self.setting)
         inputs, outputs = self.compute.image2warping(inputs, outputs, self.setting)
         outputs = self.compute.compute_loss(inputs, outputs, self.setting)
         return outputs

@@ -179,14 +179,14 @@ def test_kitti_tree_training_and_eigen_style_evaluation(G, tmp_path):
 
 
 def _trainer_losses(graph, automask=False, noise="device", n=6, lr_change_at=4, amp="none", channels_last="auto", batches=None,
-                    frame_ids=(0, -1, 1)):
+                    frame_ids=(0, -1, 1), overlap_pose=True):
     import importlib
     bench = importlib.import_module("bench")
     from model_train import trainer
     torch.manual_seed(0)
     opt = bench.make_opt(2, height=64, width=96, amp=amp, frame_ids=frame_ids)
     opt.use_automasking, opt.graph, opt.synthetic_length, opt.max_steps, opt.miopen_find = automask, graph, 16, 0, False
-    opt.noise, opt.channels_last = noise, channels_last
+    opt.noise, opt.channels_last, opt.overlap_pose = noise, channels_last, overlap_pose
     tr = trainer(opt)
     tr.setting.set_train()
     if batches is None:
@@ -226,6 +226,24 @@ def test_trainer_channels_last_follows_the_planar_trajectory(G, graph):
     assert enc.layer2[0].conv1.weight.is_contiguous(memory_format=torch.channels_last) and not enc.layer2[0].conv1.weight.is_contiguous()
     _same_trajectory(nhwc, planar)
     _same_trajectory(mixed, planar)
+
+
+@pytest.mark.parametrize("graph", [False, True])
+@pytest.mark.parametrize("amp", ["none", "bf16"])
+def test_pose_network_beside_depth_network_follows_the_sequential_trajectory(G, graph, amp):
+    """opt.overlap_pose (default): the separate pose network runs on a side stream beside the depth network -- forward in
+    trainer.batch_process, backward because autograd runs a node's backward on its forward's stream -- and joins before the loss
+    kernels.  Same numbers as one network after the other, eager and captured (fork / join become graph edges), fp32 and bf16."""
+    seq, n0, tr0 = _trainer_losses(graph, overlap_pose=False, amp=amp)
+    par, n1, tr1 = _trainer_losses(graph, overlap_pose=True, amp=amp)
+    assert n0 == n1 == 6 and tr1._pose_stream is not None and tr0._pose_stream is None
+    if amp == "none":
+        _same_trajectory(par, seq)
+    else:
+        np.testing.assert_allclose(par, seq, rtol=5e-2, atol=1e-4)
+    pa, pb = dict(tr1.setting.raw_model["pose_decoder"].named_parameters()), dict(tr0.setting.raw_model["pose_decoder"].named_parameters())
+    for k in pa:       # six Adam steps of lr 1e-4: the weights agree far inside one step's change
+        assert float((pa[k] - pb[k]).abs().max()) <= (6e-4 if amp == "none" else 3e-3), k
 
 
 def test_trainer_graph_replay_matches_eager(G):
