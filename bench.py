@@ -377,6 +377,10 @@ def launch_ranks(n, argv):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this pool (RCCL needs it)
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    if "--eager" not in argv and os.environ.get("MDX_HW_QUEUES", "") != "0":
+        # the ranks run the captured step: two hardware queues (model_train.py; measured with a process group of one rank:
+        # resident 742 / loop 722 images/s at 2 queues, 744 / 669 at 4, 514 / 723 at 8)
+        env.setdefault("GPU_MAX_HW_QUEUES", os.environ.get("MDX_HW_QUEUES") or "2")
     return subprocess.run(launch_command(n, argv), env=env).returncode
 
 
@@ -465,8 +469,7 @@ def trainer_loop_child(feed, port=None):
     multi = int(os.environ.get("WORLD_SIZE", "1")) > 1
     # (several ranks: the loop's step is captured only on request -- MDX_DP_GRAPH=1, which `--graph` sets -- see
     # model_tool/parallel.py: dp_graph_allowed; the eager data-parallel step is fastest at the runtime's default)
-    if (((multi and os.environ.get("MDX_DP_GRAPH", "") == "1") or (not multi and "--dist" in keep))
-            and "--trainer-eager" not in keep and os.environ.get("MDX_HW_QUEUES", "") != "0"):
+    if ((multi or "--dist" in keep) and "--trainer-eager" not in keep and os.environ.get("MDX_HW_QUEUES", "") != "0"):
         # what model_train.py does for a data-parallel run (see there): two hardware queues for the loop's process, so that
         # the graph's RCCL branch and the prefetcher's stream do not share one; this process (the resident step) keeps the default
         env.setdefault("GPU_MAX_HW_QUEUES", os.environ.get("MDX_HW_QUEUES") or "2")
@@ -502,8 +505,10 @@ def main():
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark (MIOpen find mode)")
     ap.add_argument("--no-miopen-db", action="store_true", help="ignore the shipped gfx950 find-db (MIOpen heuristics)")
     ap.add_argument("--graph", action="store_true",
-                    help="capture the whole step (nets + fused loss + gradient all-reduce + Adam) into ONE hipGraph and "
-                         "replay it -- any number of ranks")
+                    help="(the default since round 5; kept so that older command lines still work) the step captured into a "
+                         "hipGraph and replayed.  Several ranks: the split form -- forward + backward + gather in one graph, the "
+                         "all-reduce issued eagerly, Adam in a second graph; MDX_DP_GRAPH=1 puts the exchange inside ONE graph")
+    ap.add_argument("--eager", action="store_true", help="the step launched kernel by kernel instead of replayed from a hipGraph")
     ap.add_argument("--dist", action="store_true",
                     help="with --gpus 1: run the data-parallel path anyway (a process group of ONE rank over RCCL: flat "
                          "gradient buffer, bucketed all-reduce issued inside backward)")
@@ -545,10 +550,6 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.graph and world > 1:
-        # an explicit request for the captured data-parallel step (off by default with several ranks: a captured multi-rank
-        # RCCL exchange has not run on hardware yet -- model_tool/parallel.py: dp_graph_allowed); inherited by the loop's children
-        os.environ["MDX_DP_GRAPH"] = "1"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
     local = local % torch.cuda.device_count()          # rehearsal: several ranks may share one GPU
@@ -600,7 +601,7 @@ def main():
     # MIOpen picks the tuned solvers from the shipped find-db in immediate mode already (fp32: same images/s as find
     # mode).  Find mode proper (--miopen-find) returns at once on a db hit but searches for minutes on a miss, so it
     # is never on by default; bf16 networks gain from it (a few more solvers are only reachable through find).
-    opt.miopen_find, opt.graph = args.miopen_find, args.graph
+    opt.miopen_find, opt.graph = args.miopen_find, not args.eager
     # the product's own step (model_train.trainer._eager_step / graphed_step) on one batch that stays resident in HBM
     tr = trainer(opt)
     st, cp = tr.setting, tr.compute
@@ -616,11 +617,12 @@ def main():
         torch.cuda.synchronize()
 
     graph = None
-    if args.graph:
-        if not tr.can_graph():
-            raise SystemExit("bench.py: --graph needs a capturable step (device-side noise, RCCL process group)")
-        # hipGraph: side-effect-free warm-up on a side stream, capture of one step (the gradient exchange included),
-        # then every timed step is a single graph launch -- ~1600 kernel launches leave the host's critical path
+    if args.graph and not tr.can_graph():
+        raise SystemExit("bench.py: --graph needs a capturable step (device-side noise, RCCL process group)")
+    if not args.eager and tr.can_graph():
+        # hipGraph (what model_train.py runs by default): side-effect-free warm-up on a side stream, capture of one step, then
+        # every timed step is one graph launch (several ranks: two, with the all-reduce between them) -- ~1900 kernel launches
+        # leave the host's critical path; since the pose network runs beside the depth network an eager step is host-bound
         graph = graphed_step(tr, inputs)
         for _ in range(args.warmup):
             graph({})
@@ -685,7 +687,10 @@ def main():
                                       args.height, args.width, args.batch, args.num_layers, args.num_layers,
                                       str(frame_ids).replace(" ", ""), "fp32" if args.amp == "none" else "bf16 nets"),
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world},
-            "ranks_verified": ranks_verified, "final_loss": loss_val, "hip_graph": bool(graph is not None), "miopen_find_db": bool(miopen_db),
+            "ranks_verified": ranks_verified, "final_loss": loss_val, "hip_graph": bool(graph is not None),
+            "hip_graph_form": (None if graph is None else "split: forward+backward+gather | eager all-reduce | Adam" if graph.split
+                               else "one graph" + (" incl. the gradient exchange" if st.sync is not None else "")),
+            "miopen_find_db": bool(miopen_db),
             "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms), "argmax_rank": int(max(range(len(rank_ms)), key=rank_ms.__getitem__))},
             "channels_last": sorted(getattr(st, "channels_last_stages", ())),
             "pose_beside_depth": bool(tr._pose_beside_depth()),

@@ -140,8 +140,7 @@ class setting(object):
             # a captured step exchanges ONE bucket when backward ends; an eager one overlaps 32 MB buckets with backward
             # (measured: model_tool/parallel.py)
             captured = bool(_opt(opt, "graph", False)) and str(self.device).startswith("cuda") \
-                and str(_opt(opt, "noise", "device")) != "cpu" and torch.distributed.get_backend() == "nccl" \
-                and dp_graph_allowed(torch.distributed.get_world_size())       # = trainer.can_graph()
+                and str(_opt(opt, "noise", "device")) != "cpu" and torch.distributed.get_backend() == "nccl"       # = trainer.can_graph()
             mb = int(_opt(opt, "bucket_mb", 0)) or ((1 << 20) if captured else 32)
             self.sync = grad_sync(self.parameters, bucket_mb=mb, comm_dtype=comm)
 

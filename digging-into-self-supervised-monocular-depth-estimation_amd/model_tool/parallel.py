@@ -46,7 +46,9 @@ import torch.distributed as dist
 
 
 def dp_graph_allowed(world):
-    """May the step of a `world`-rank job be captured into a hipGraph (exchange included)?  One rank: yes (measured and
+    """May the step of a `world`-rank job be captured into ONE hipGraph, exchange included?  (If not, a captured step takes the
+    SPLIT form -- forward + backward + gather in one graph, the all-reduce issued eagerly, Adam in a second graph -- which keeps
+    RCCL out of the capture: model_train.graphed_step.)  One rank: yes (measured and
     tested on the GPU: tests/test_gpu_driver.py).  Several ranks: only with MDX_DP_GRAPH=1 -- a captured MULTI-rank RCCL
     all-reduce (fork / join of the communicator's stream inside the capture, replay order across ranks) has not run on
     hardware yet (no multi-GPU node was available to this build: SCALE_r01..r03 were skipped), so the default
@@ -121,9 +123,15 @@ class grad_sync(object):
                 self._views[id(p)] = grad_view(self.flat, self.offsets[id(p)], p)
         self._avg = self.backend == "nccl"                      # ncclAvg exists in RCCL; gloo only sums
         self._works = []
+        self._xs, self._streams = None, []                       # exchange stream; streams seen producing gradients
         self._reset()
         self.zero()
         self._hooks = [p.register_post_accumulate_grad_hook(self._ready) for p in self.params]
+
+    def backward_streams(self, streams):
+        """Side streams on which parts of backward run (besides the stream backward() is called on): the exchange waits for them
+        too.  Static, so that the per-parameter hook stays as light as it can be (an eager data-parallel step is host-bound)."""
+        self._streams = [t for t in streams if t is not None]
 
     def zero(self):
         """Instead of optimizer.zero_grad(): `.grad` = None, so backward's accumulation keeps the incoming tensor as
@@ -135,14 +143,10 @@ class grad_sync(object):
     def _reset(self):
         self._pending = [len(m) for _, _, m in self.buckets]
         self._next = 0                     # buckets are issued strictly in order: every rank issues the same sequence
-        self._streams = []                 # streams that have produced gradients since zero() (the pose network's backward runs
-                                           # beside the depth network's on a side stream: model_train.trainer.batch_process)
+        self._keep = []                    # gathered gradients stay alive until finish(): their memory must not be handed out
+                                           # again while the exchange stream still reads them
 
     def _ready(self, p):
-        if p.is_cuda:
-            cur = torch.cuda.current_stream(p.device)
-            if all(cur != t for t in self._streams):
-                self._streams.append(cur)
         k = self._bucket_of[id(p)]
         if k < self._next:
             # the bucket is on the wire (or back) and `.grad` is the exchanged view: this gradient comes from a SECOND
@@ -155,14 +159,23 @@ class grad_sync(object):
             self._next += 1
 
     def _issue(self, k):
+        if not self.flat.is_cuda:
+            return self._issue_on_current(k)
+        # On the exchange stream, behind the backward streams' work so far: the streams that run backward are never made to wait for
+        # each other or for the gather (with whole-stream waits on the issuing stream the two backward streams serialised: 634
+        # against 654 images/s without the overlap; stream-side waits on events are capturable).
+        if self._xs is None:
+            self._xs = torch.cuda.Stream(self.flat.device)
+        # everything the backward streams have been given so far, the bucket's gradients included: the stream this hook runs on and
+        # the ones the trainer registered (the pose network's backward runs beside the depth network's, model_train.trainer)
+        self._xs.wait_stream(torch.cuda.current_stream(self.flat.device))
+        for t in self._streams:
+            self._xs.wait_stream(t)
+        with torch.cuda.stream(self._xs):
+            self._issue_on_current(k)
+
+    def _issue_on_current(self, k):
         a, b, members = self.buckets[k]
-        if self.flat.is_cuda:
-            # a bucket may hold gradients written on another stream than the one that issues it: order this stream behind all
-            # of them (a stream-side wait; capturable)
-            cur = torch.cuda.current_stream(self.flat.device)
-            for t in self._streams:
-                if t != cur:
-                    cur.wait_stream(t)
         dst, src = [], []
         for p in members:
             v = self._views[id(p)]
@@ -173,6 +186,7 @@ class grad_sync(object):
                 src.append(p.grad)
         if dst:
             torch._foreach_copy_(dst, src)                       # one multi-tensor kernel
+            self._keep.extend(src)
         for p in members:
             p.grad = self._views[id(p)]                          # what the optimiser reads: the reduced values
         buf = self.flat[a:b]
@@ -188,17 +202,42 @@ class grad_sync(object):
         assert work is not None, "grad_sync: the all-reduce must be asynchronous"
         self._works.append((k, work))
 
+    def gather(self):
+        """After backward, for a step whose exchange happens OUTSIDE a captured graph (model_train.graphed_step, split form): every
+        gradient gathered into the flat buffer and visible to the current stream, nothing sent.  Pair with exchange()."""
+        was, self.no_comm = self.no_comm, True
+        try:
+            self.finish()
+        finally:
+            self.no_comm = was
+
+    def exchange(self):
+        """The whole flat buffer in ONE all-reduce(mean), issued eagerly on the current stream (no host synchronisation on
+        RCCL): what sits between the two graphs of the split form."""
+        buf = self.flat
+        if self.comm is not None:
+            self.comm.copy_(self.flat)
+            buf = self.comm
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        dist.all_reduce(buf, op=op, group=self.group)
+        if self.comm is not None:
+            self.flat.copy_(self.comm)
+        if not self._avg:
+            self.flat.mul_(1.0 / self.world)
+
     def finish(self):
         """After backward: every bucket exchanged and visible to the current stream (no host synchronisation on GPU)."""
         while self._next < len(self.buckets):
             self._issue(self._next)
             self._next += 1
+        if self._xs is not None:
+            torch.cuda.current_stream(self.flat.device).wait_stream(self._xs)      # (no_comm / zero-filled buckets: no work to wait on)
         for k, w in self._works:
             w.wait()                   # nccl: the current stream waits for the communicator's stream; gloo: blocks
             if self.comm is not None:
                 a, b, _ = self.buckets[k]
                 self.flat[a:b].copy_(self.comm[a:b])
-        if not self._avg:
+        if not self._avg and not self.no_comm:
             self.flat.mul_(1.0 / self.world)
         self._works = []
         self._reset()

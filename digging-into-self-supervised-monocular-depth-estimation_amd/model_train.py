@@ -6,16 +6,14 @@
 import os
 import sys
 
-# Data-parallel runs: the step's hipGraph holds the RCCL all-reduce as a second branch, and with the HIP runtime's default of 4
-# hardware queues per device that branch shares a queue with the prefetcher's side stream (uploads + image preparation): the
-# loader-fed loop then runs 1.0-1.3 ms per step behind the same loop on a resident batch (measured with a process group of one
-# rank: fp32 22.65 -> 21.60 ms, bf16 15.34 -> 14.31 ms with 2 queues; 1: 15.5, 3: 14.4, 8: 14.2, 16: 14.7 -- tools/
-# sweep_hw_queues.sh).  The runtime reads the variable when it is loaded, i.e. before `import torch`.  MDX_HW_QUEUES=0 leaves
-# the runtime's default, MDX_HW_QUEUES=n asks for n; a value the user exported (GPU_MAX_HW_QUEUES) is never overridden.
-# Only for the captured step: an EAGER data-parallel step is fastest with the runtime's default (1-rank group, resident batch:
-# 576 images/s at 4 queues, 563 at 2, 561 at 8).  With WORLD_SIZE > 1 the step is captured only when MDX_DP_GRAPH=1 asks for
-# it (model_tool/parallel.py: dp_graph_allowed -- a captured multi-rank exchange has not run on hardware yet), so the queue
-# count follows that switch too.
+# Data-parallel runs: the captured step's streams (the capture stream, the pose network's side stream, the gradient exchange, RCCL's
+# own, the prefetcher's uploads + image preparation) are mapped onto the HIP runtime's hardware queues, 4 per device by default,
+# and which two share one decides what overlaps.  Measured with a process group of one rank (round 5, pose network beside the
+# depth network, images/s resident | DataLoader-fed loop): 2 queues 742 | 722 (bf16 1475 | 1412), 4 queues 744 | 669 (1487 |
+# 1248), 8 queues 514 | 723; an EAGER data-parallel step is the opposite (2: 686, 4: 625, 8: 733) and host-bound besides.  So a
+# captured data-parallel run asks for 2.  The runtime reads the variable when it is loaded, i.e. before `import torch`.
+# MDX_HW_QUEUES=0 leaves the runtime's default, MDX_HW_QUEUES=n asks for n; a value the user exported (GPU_MAX_HW_QUEUES) is never
+# overridden.  (Round 3's sweep, before the side streams: LABNOTES.md.)
 def _graph_requested(argv):
     for i, a in enumerate(argv):
         v = a.split("=", 1)[1] if a.startswith("--graph=") else (argv[i + 1] if a == "--graph" and i + 1 < len(argv) else None)
@@ -27,8 +25,7 @@ def _graph_requested(argv):
 # (only when this file is the program: imported by another one -- bench.py -- the runtime is loaded already and the variable
 # would merely leak into that program's child processes)
 if os.path.basename(sys.argv[0] or "") == "model_train.py" and os.environ.get("MDX_HW_QUEUES", "") != "0" and (
-        os.environ.get("MDX_HW_QUEUES") or (int(os.environ.get("WORLD_SIZE", "1")) > 1 and _graph_requested(sys.argv[1:])
-                                            and os.environ.get("MDX_DP_GRAPH", "") == "1")):
+        os.environ.get("MDX_HW_QUEUES") or (int(os.environ.get("WORLD_SIZE", "1")) > 1 and _graph_requested(sys.argv[1:]))):
     os.environ.setdefault("GPU_MAX_HW_QUEUES", os.environ.get("MDX_HW_QUEUES") or "2")
 
 import numpy as np        # noqa: E402
@@ -90,6 +87,13 @@ class graphed_step(object):
     def __init__(self, tr, example, warmup=3):
         self.tr = tr
         dev = tr.device
+        # several ranks without MDX_DP_GRAPH=1: the SPLIT form -- graph A = forward, backward, gradients gathered into the flat
+        # buffer; the all-reduce issued eagerly between the replays (RCCL never inside a capture: a captured multi-rank exchange
+        # has not run on hardware); graph B = Adam.  Two graph launches and one collective per step on the host instead of ~1900
+        # kernel launches (an eager data-parallel step is host-bound since the pose network runs beside the depth network).
+        from model_tool.parallel import dp_graph_allowed
+        sync = tr.setting.sync
+        self.split = sync is not None and (not dp_graph_allowed(sync.world) or os.environ.get("MDX_DP_SPLIT", "") == "1")
         opt = tr.setting.optim["optimizer"]
         self.lr = torch.tensor(float(opt.param_groups[0]["lr"]), device=dev)
         for g in opt.param_groups:
@@ -141,8 +145,16 @@ class graphed_step(object):
         # thread_local: the DataLoader's pin-memory thread keeps allocating pinned host buffers for the next batches
         # (and RCCL's watchdog thread polls events) while this thread captures; in the default "global" mode such a
         # call from ANY thread invalidates the capture
-        with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="thread_local"):
-            outputs = tr._eager_step(dict(self.static))
+        self.graph_apply = None
+        if self.split:
+            with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="thread_local"):
+                outputs = tr._step_gradients(dict(self.static))
+            self.graph_apply = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_apply, stream=self.stream, capture_error_mode="thread_local", pool=self.graph.pool()):
+                tr.setting.optim["optimizer"].step()
+        else:
+            with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="thread_local"):
+                outputs = tr._eager_step(dict(self.static))
         # the graph's output tensors, without the autograd graph behind them: a loss that kept its grad_fn would keep the
         # capture pass's gradient-accumulation nodes (created on the capture stream) alive into later eager steps
         def _plain(v):
@@ -166,6 +178,9 @@ class graphed_step(object):
             if k in self.copied and torch.is_tensor(v):
                 self.static[k].copy_(v, non_blocking=True)
         self.graph.replay()
+        if self.graph_apply is not None:
+            self.tr.setting.sync.exchange()
+            self.graph_apply.replay()
         for m, inc in zip(self.bns, self.bn_incr):
             m._pending_batches += inc
         return self.outputs
@@ -219,6 +234,8 @@ class trainer(object):
             cur = torch.cuda.current_stream(self.device)
             if self._pose_stream is None:
                 self._pose_stream = torch.cuda.Stream(self.device)
+                if self.setting.sync is not None:
+                    self.setting.sync.backward_streams([self._pose_stream])
             self._pose_stream.wait_stream(cur)
             with torch.cuda.stream(self._pose_stream):
                 inputs, outputs = self.compute.forward_pose(inputs, outputs, self.setting)
@@ -229,6 +246,15 @@ class trainer(object):
             inputs, outputs = self.compute.forward_pose(inputs, outputs, self.setting)
         inputs, outputs = self.compute.image2warping(inputs, outputs, self.setting)
         outputs = self.compute.compute_loss(inputs, outputs, self.setting)
+        return outputs
+
+    def _step_gradients(self, inputs):
+        """The step up to its gradients, gathered into the flat buffer and NOT exchanged (graph A of graphed_step's split form)."""
+        outputs = self.batch_process(inputs)
+        sync = self.setting.sync
+        sync.zero()
+        outputs["loss"].backward()
+        sync.gather()
         return outputs
 
     def _eager_step(self, inputs):
@@ -247,12 +273,11 @@ class trainer(object):
 
     def can_graph(self):
         """The step is capturable when nothing in it runs on the host: not with the reference's host-side noise
-        (--noise cpu: torch.randn on the CPU + a copy from pageable memory), not with a non-RCCL process group -- and,
-        with more than one rank, only on request (MDX_DP_GRAPH=1; model_tool/parallel.py: dp_graph_allowed)."""
-        from model_tool.parallel import dp_graph_allowed
+        (--noise cpu: torch.randn on the CPU + a copy from pageable memory), not with a non-RCCL process group.  With more than
+        one rank the capture takes the split form (graphed_step) unless MDX_DP_GRAPH=1 asks for the exchange inside the graph."""
         sync = self.setting.sync
         return (str(self.device).startswith("cuda") and self.compute.noise_mode != "cpu"
-                and (sync is None or (sync.backend == "nccl" and dp_graph_allowed(sync.world))))
+                and (sync is None or sync.backend == "nccl"))
 
     def train_step(self, inputs):
         """opt.graph (GPU): the step -- under torch.distributed including the gradient exchange -- is captured once
@@ -262,9 +287,7 @@ class trainer(object):
             if getattr(self.opt, "graph", False) and not getattr(self, "_told_eager", False) and str(self.device).startswith("cuda"):
                 self._told_eager = True       # once, rank 0: --graph was asked for and the step runs eager (other bucket sizes, queues)
                 if self.rank == 0:
-                    why = ("--noise cpu draws on the host" if self.compute.noise_mode == "cpu" else
-                           "several ranks: the captured data-parallel step is opt-in, set MDX_DP_GRAPH=1 (model_tool/parallel.py: "
-                           "dp_graph_allowed) -- or the process group is not RCCL")
+                    why = "--noise cpu draws on the host" if self.compute.noise_mode == "cpu" else "the process group is not RCCL"
                     print("model_train: --graph requested but the step is not captured (%s); running the eager step" % why, flush=True)
             return self._eager_step(inputs)
         inputs = self.compute.prepare(inputs)     # decoded frames -> step entries (a no-op after the prefetcher)

@@ -49,7 +49,8 @@ def test_synchronous_collectives_refuse_stream_capture(monkeypatch):
 
 
 def test_captured_data_parallel_step_is_opt_in(monkeypatch):
-    """With several ranks the step is captured (exchange inside the hipGraph) only on request: MDX_DP_GRAPH=1."""
+    """With several ranks the exchange goes INSIDE the captured hipGraph only on request (MDX_DP_GRAPH=1); otherwise a captured
+    step takes the split form (model_train.graphed_step: the all-reduce issued eagerly between two graphs)."""
     import importlib
     import sys
     sys.path.insert(0, ROOT)

@@ -324,6 +324,33 @@ def test_trainer_captured_step_with_rccl_exchange(G, rccl_group_of_one):
         tr.setting.sync.detach()
 
 
+@pytest.mark.parametrize("amp", ["none", "bf16"])
+def test_trainer_split_capture_keeps_rccl_out_of_the_graph(G, rccl_group_of_one, monkeypatch, amp):
+    """What a multi-rank job runs by default: graph A = forward, backward, gradients gathered into the flat buffer; the
+    all-reduce issued EAGERLY between the replays (no RCCL call inside a capture); graph B = Adam.  Forced here with a group of
+    one rank (MDX_DP_SPLIT=1; with several ranks it is the form whenever MDX_DP_GRAPH is not 1): same trajectory as the eager
+    data-parallel step, the exchange really runs (the flat buffer is what Adam reads), batch-norm counters advance."""
+    eager, n_eager, tr_e = _trainer_losses(False, amp=amp)
+    monkeypatch.setenv("MDX_DP_SPLIT", "1")
+    calls = []
+    real = rccl_group_of_one.all_reduce
+    monkeypatch.setattr(rccl_group_of_one, "all_reduce", lambda *a, **k: (calls.append(torch.cuda.is_current_stream_capturing()), real(*a, **k))[1])
+    split, n_split, tr_s = _trainer_losses(True, amp=amp)
+    g = tr_s._graphed
+    assert g is not None and g.split and g.graph_apply is not None and len(tr_s.setting.sync.buckets) == 1
+    assert n_split == n_eager == 6
+    assert calls and not any(calls), "an all-reduce ran inside a capture"
+    assert sum(1 for c in calls) >= 6          # one per replayed step (+ the warm-up steps' bucketed ones)
+    if amp == "none":
+        _same_trajectory(split, eager)
+    else:
+        np.testing.assert_allclose(split, eager, rtol=5e-2, atol=1e-4)
+    sync = tr_s.setting.sync
+    assert all(p.grad.data_ptr() == sync.flat.data_ptr() + 4 * sync.offsets[id(p)] for p in sync.params)
+    for tr in (tr_e, tr_s):
+        tr.setting.sync.detach()
+
+
 def test_synchronous_collectives_refuse_capture_on_gpu(G, rccl_group_of_one):
     """VERDICT r3 weak #6 (gpurun_out/r3b/dist_graph_blocking.err: core dump): a blocking collective inside a capture must
     raise in the caller -- and the process, the process group and the GPU must be usable afterwards."""
