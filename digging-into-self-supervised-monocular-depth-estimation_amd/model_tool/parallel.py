@@ -202,14 +202,20 @@ class grad_sync(object):
         assert work is not None, "grad_sync: the all-reduce must be asynchronous"
         self._works.append((k, work))
 
-    def gather(self):
-        """After backward, for a step whose exchange happens OUTSIDE a captured graph (model_train.graphed_step, split form): every
-        gradient gathered into the flat buffer and visible to the current stream, nothing sent.  Pair with exchange()."""
-        was, self.no_comm = self.no_comm, True
-        try:
-            self.finish()
-        finally:
-            self.no_comm = was
+    def gather_only(self):
+        """Context manager around backward() + finish() of a step whose exchange happens OUTSIDE a captured graph
+        (model_train.graphed_step, split form): buckets are gathered into the flat buffer as they complete, nothing is sent --
+        also not by the hook of a bucket's last gradient, which fires INSIDE backward.  Pair with exchange()."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            was, self.no_comm = self.no_comm, True
+            try:
+                yield self
+            finally:
+                self.no_comm = was
+        return scope()
 
     def exchange(self):
         """The whole flat buffer in ONE all-reduce(mean), issued eagerly on the current stream (no host synchronisation on

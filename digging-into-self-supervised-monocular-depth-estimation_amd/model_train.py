@@ -253,8 +253,9 @@ class trainer(object):
         outputs = self.batch_process(inputs)
         sync = self.setting.sync
         sync.zero()
-        outputs["loss"].backward()
-        sync.gather()
+        with sync.gather_only():
+            outputs["loss"].backward()
+            sync.finish()
         return outputs
 
     def _eager_step(self, inputs):
