@@ -650,7 +650,7 @@ def main():
         # (every rank: the eager step contains the exchange)
         timing = {"fwd": [], "bwd": [], "train": []}
         F.TIMING = timing if rank == 0 else None
-        for _ in range(5):
+        for _ in range(20):
             step()
         torch.cuda.synchronize()
         F.TIMING = None
@@ -698,7 +698,7 @@ def main():
         if st.sync is not None:
             line["gradient_exchange"] = {"backend": "rccl" if st.sync.backend == "nccl" else st.sync.backend,
                                          "buckets": len(st.sync.buckets), "bytes": 4 * st.sync.flat.numel(),
-                                         "comm_dtype": args.grad_comm, "in_graph": bool(graph is not None),
+                                         "comm_dtype": args.grad_comm, "in_graph": bool(graph is not None and not graph.split),
                                          "what": "flat gradient buffer; bucketed all-reduce(mean) issued from inside backward"}
         if not args.no_roofline and timing is not None:
             line.update(roofline_blocks(args, opt, frame_ids, F.timing_summary(timing)))
@@ -706,7 +706,7 @@ def main():
                 line.setdefault("roofline_other", []).extend(network_kernel_roofline(args, opt))
             except Exception as exc:  # noqa: BLE001  (a side measurement never takes the line down)
                 line.setdefault("roofline_other", []).append({"error": "network kernel measurement failed: %r" % (exc,)})
-    if not args.no_trainer_loop and (graph is None or distributed):
+    if not args.no_trainer_loop:
         graph = None
         del tr, st, cp, inputs
         import gc
