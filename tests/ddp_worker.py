@@ -135,6 +135,27 @@ def main():
     run(st.model).backward()
     st.sync.finish()
     assert check_grads() < tol
+    # 2c. the split form a multi-rank captured step takes (model_train.graphed_step): gradients gathered without any exchange --
+    #     also not from the hooks inside backward -- then ONE all-reduce of the flat buffer: the same rank-mean gradients
+    calls = []
+    real_all_reduce = dist.all_reduce
+    dist.all_reduce = lambda *a, **k: (calls.append(1), real_all_reduce(*a, **k))[1]
+    try:
+        st.sync.zero()
+        with st.sync.gather_only():
+            run(st.model).backward()
+            st.sync.finish()
+        assert not calls, "gather_only() sent something"
+        local_only = st.sync.flat.clone()
+        st.sync.exchange()
+        assert len(calls) == 1
+    finally:
+        dist.all_reduce = real_all_reduce
+    assert all(p.grad.data_ptr() == st.sync.flat.data_ptr() + 4 * st.sync.offsets[id(p)] for p in st.sync.params)
+    assert check_grads() < tol, "split form: gradients are not the rank mean"
+    probe = local_only.clone()
+    dist.all_reduce(probe)
+    assert float((probe / world - st.sync.flat).abs().max()) <= tol * float(st.sync.flat.abs().max() + 1e-12)
     # 3. after the step every rank holds the same parameters, and they are the single-process Adam step on the mean gradient
     #    (element pairing by layout: with --channels_last a contiguous gradient view would pair the wrong elements)
     ref_opt = torch.optim.Adam([p for m in local.values() for p in m.parameters() if p.requires_grad], float(o.learning_rate))
