@@ -16,10 +16,11 @@ def options(argv=None):
     p.add_argument("--epoch", type=int, default=24)
     p.add_argument("--batch", type=int, default=12)
     p.add_argument("--prepetch", type=int, default=2)
-    p.add_argument("--num_workers", type=int, default=12,
-                   help="DataLoader workers per process (reference default, model_option.py:32-34).  With --gpu_image_prep 12 "
-                        "workers deliver ~700-860 samples/s, 16 ~1100 (tools/loader_cost.py --workers N); -1 = sized for "
-                        "this rank (12, or 16 with --amp bf16 whose step consumes ~900 samples/s, capped by the host share)")
+    p.add_argument("--num_workers", type=int, default=None,
+                   help="DataLoader workers per process.  Default: 12 (the reference's, model_option.py:32-34) for fp32 networks, 24 "
+                        "with --amp bf16, whose step consumes ~1500 samples/s (12 workers deliver ~700-860 with --gpu_image_prep, 16 "
+                        "~1100, 24 ~1200 on a 16-core share: tools/loader_cost.py --workers N); -1 = sized from this rank's share of "
+                        "the host cores")
     p.add_argument("--learning_rate", type=float, default=1e-4)
     p.add_argument("--scheduler_step", type=int, default=15)
     p.add_argument("--disp_smoothness", type=float, default=1e-3)
@@ -75,4 +76,7 @@ def options(argv=None):
     p.add_argument("--miopen_find", action="store_true",
                    help="cudnn.benchmark: MIOpen find mode (a search of minutes for shapes that are not in the "
                         "shipped find-db; the default, immediate mode, already uses the db)")
-    return p.parse_args(argv)
+    o = p.parse_args(argv)
+    if o.num_workers is None:
+        o.num_workers = 24 if o.amp == "bf16" else 12
+    return o

@@ -85,11 +85,11 @@ class setting(object):
             shuffle = False
         workers = opt.num_workers
         if workers < 0:
-            # -1 = sized for this rank: the rank's share of the host cores less two (main + pin-memory thread), at most what
-            # the step consumes -- 12 workers deliver ~700-860 samples/s with the GPU image preparation (an fp32 step takes
-            # ~585), 16 deliver ~1100 (a bf16 step ~900): tools/loader_cost.py --workers N
+            # -1 = sized for this rank: at most what the step consumes -- with the GPU image preparation 12 workers deliver ~700-860
+            # samples/s, 16 ~1100, 24 ~1200 on a 16-core share (tools/loader_cost.py --workers N; the decoders wait on I/O, a few
+            # more workers than cores pay); an fp32 step takes ~750 samples/s, a bf16 step ~1500 (round 5)
             share = max(2, len(os.sched_getaffinity(0)) // max(1, min(self.world_size, torch.cuda.device_count() or 1)))
-            workers = max(2, min(16 if str(_opt(opt, "amp", "none")) == "bf16" else 12, share - 2))
+            workers = max(2, min(24, share + share // 2) if str(_opt(opt, "amp", "none")) == "bf16" else min(16, share))
         return DataLoader(dataset, opt.batch, shuffle, sampler=sampler, num_workers=workers,
                           drop_last=True, pin_memory=str(self.device).startswith("cuda"),
                           collate_fn=(collate_raw_step_keys if getattr(dataset, "gpu_prep", False) or getattr(dataset, "raw", False)

@@ -115,6 +115,24 @@ def test_resize_rows_form_equals_gather_form(G, IP):
             assert np.array_equal(a[n].cpu().numpy(), orc.resample_lanczos(imgs[n], out[0], out[1], flips[n]).transpose(2, 0, 1)), ((h, w), out, n)
 
 
+def test_resize_reads_nothing_behind_an_image(G, IP):
+    """The bytes beside and below an image in its slot -- and behind the last pixel of its last row (the rows form
+    treated in_h * in_stride bytes as readable, a crop view of a larger image has nothing there) -- are not part of the input:
+    the same frames in slots padded with 0 and with 255 give the same bytes, both passes' forms, flipped and not."""
+    rng = np.random.default_rng(83)
+    for (h, w), out in [((70, 1242), (36, 640)), ((33, 301), (20, 299)), ((9, 40), (9, 90)), ((17, 23), (5, 7))]:
+        imgs = [_natural(rng, h, w), _natural(rng, h - 3, w - 7)]
+        sizes, flips = [(h, w), (h - 3, w - 7)], [False, True]
+        a0 = _stack(imgs)
+        a1 = np.full_like(a0, 255)
+        for n, i in enumerate(imgs):
+            a1[n, : i.shape[0], : i.shape[1]] = i
+        for plans in (IP.plan_cache("cuda:0"), IP.plan_cache("cuda:0", cols=False)):
+            r0 = IP.resize_lanczos(plans, torch.from_numpy(a0).cuda(), sizes, flips, out, want_u8=True)[0]
+            r1 = IP.resize_lanczos(plans, torch.from_numpy(a1).cuda(), sizes, flips, out, want_u8=True)[0]
+            assert torch.equal(r0, r1), ((h, w), out)
+
+
 def test_resize_wide_source(G, IP):
     """a source 350x wider than its output (2101 taps per column): beyond the rows form's LDS tile, the gather form."""
     rng = np.random.default_rng(77)
