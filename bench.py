@@ -564,9 +564,9 @@ def main():
         except (OSError, ValueError, IndexError):
             pass
         share = max(2, cores // max(1, min(world, torch.cuda.device_count())))
-        # bf16 networks consume ~900 samples/s: a few workers more than cores cover the decoders' waits (one set on 16 cores:
-        # 1117 samples/s with 16 workers, 1214 with 24 -- profiles/r04_loader_8ranks.json)
-        args.workers = max(2, min(24, share + share // 2) if args.amp == "bf16" else min(12, share - 2))
+        # an fp32 step consumes ~750 samples/s, a bf16 step ~1500 (round 5); one loader set on 16 cores delivers 700-860 with 12
+        # workers, 1117 with 16, 1214 with 24 (a few workers more than cores cover the decoders' waits: profiles/r04_loader_8ranks.json)
+        args.workers = max(2, min(24, share + share // 2) if args.amp == "bf16" else min(16, share))
     backend = os.environ.get("MDX_DIST_BACKEND", "nccl")       # "nccl" is RCCL on ROCm; "gloo" only to rehearse
     if world > 1 or args.dist:
         kw = {}
