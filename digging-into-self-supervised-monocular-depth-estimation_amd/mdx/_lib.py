@@ -53,6 +53,8 @@ SYMBOLS = {
     "mdx_grid_sample_border_fwd": C.c_int, "mdx_grid_sample_border_bwd": C.c_int,
     "mdx_reprojection_loss_fwd": C.c_int, "mdx_reprojection_loss_bwd": C.c_int, "mdx_ssim_fwd": C.c_int, "mdx_ssim_bwd": C.c_int,
     "mdx_min_automask_fwd": C.c_int,
+    "mdx_loss_total_fwd": C.c_int, "mdx_loss_total_bwd": C.c_int,
+    "mdx_pose_projection_fwd": C.c_int, "mdx_pose_projection_bwd": C.c_int,
     "mdx_event_create": C.c_void_p, "mdx_event_destroy": None, "mdx_event_elapsed_us": C.c_int,
     "mdx_photometric_fwd_timed": C.c_int, "mdx_photometric_bwd_timed": C.c_int,
     "mdx_decoder_glue_fwd": C.c_int, "mdx_decoder_glue_bwd": C.c_int, "mdx_decoder_glue_workspace_bytes": C.c_size_t,

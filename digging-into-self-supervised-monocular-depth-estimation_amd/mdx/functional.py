@@ -226,6 +226,54 @@ def photometric_prologue(target, sources, nscales, noises=None, rng=None, automa
     return dict(tstat=tstat, bidfi=bidfi, ident=ident, rng=(rng if noises is None else None))
 
 
+def _train_launch(cfg, target, invK, ident, noises, sources, Pl, disps):
+    """The launch behind _PhotometricTrain and _TrainLoss: every scale's photometric term (and, with cfg['grads'], its
+    unit-upstream gradients gdisp / gP) in one launch.  Returns a dict of the buffers it filled."""
+    nsc = len(disps)
+    disps = [_f32c(x) for x in disps]
+    target, invK = _f32c(target), _f32c(invK)
+    sources = [_f32c(x) for x in sources]
+    per_scale_P = len(Pl) > 1
+    Ps = [_f32c(x) for x in Pl] if per_scale_P else [_f32c(Pl[0])] * nsc
+    B, _, H, W = target.shape
+    S = len(sources)
+    automask = cfg["automask"]
+    dev = target.device
+    d = _lib.make_train_desc(B, H, W, S, [tuple(x.shape[2:]) for x in disps], automask, cfg["min_depth"],
+                             cfg["max_depth"], cfg.get("rows_per_chunk", 0))
+    src = _lib.make_sources(sources)
+    pre = cfg.get("pre")
+    if automask and pre is None:
+        ident = _f32c(ident)
+        noises = [_f32c(x) for x in noises]
+    idx = [torch.empty(B, H, W, device=dev, dtype=torch.uint8) for _ in range(nsc)]
+    sums = torch.empty(nsc, device=dev, dtype=torch.float32)
+    grads = cfg.get("grads", True)         # False: every scale's forward alone (validation / torch.no_grad())
+    gdisp = [torch.empty_like(x) for x in disps] if grads else None
+    gP = torch.empty(nsc, S, B, 3, 4, device=dev, dtype=torch.float32) if grads else None
+    depth0 = torch.empty(B, 1, H, W, device=dev, dtype=torch.float32) if cfg.get("need_depth") else None
+    to_opt = [torch.empty(B, H, W, device=dev, dtype=torch.float32) for _ in range(nsc)] \
+        if cfg.get("need_to_opt") else None
+    nws = lib().mdx_photometric_train_workspace_bytes(C.byref(d))
+    ws = torch.empty(nws // 16 + 1, 2, dtype=torch.float64, device=dev)
+    hook = _timing_hook("train" if grads else "eval")
+    tail = (_lib.ptr_array(idx, torch.uint8), ptr(sums), _lib.ptr_array(gdisp) if grads else None,
+            ptr(gP) if grads else None, ptr(depth0, optional=True),
+            _lib.ptr_array(to_opt) if to_opt is not None else None, ptr(ws, torch.float64), C.c_size_t(nws), stream(),
+            C.byref(hook) if hook is not None else None)
+    if pre is not None:
+        check(lib().mdx_photometric_train_pre(
+            C.byref(d), _lib.ptr_array(disps), ptr(target), C.byref(src), ptr(invK), _lib.ptr_array(Ps),
+            ptr(pre["tstat"]), _lib.ptr_array(pre["bidfi"]) if automask else None,
+            pre["rng"].ptr() if pre.get("rng") is not None else None, *tail), "mdx_photometric_train_pre")
+    else:
+        check(lib().mdx_photometric_train(
+            C.byref(d), _lib.ptr_array(disps), ptr(target), C.byref(src), ptr(invK), _lib.ptr_array(Ps),
+            ptr(ident) if automask else None, _lib.ptr_array(noises) if automask else None, *tail),
+            "mdx_photometric_train")
+    return dict(sums=sums, idx=idx, gdisp=gdisp, gP=gP, depth0=depth0, to_opt=to_opt, per_scale_P=per_scale_P, pixels=B * H * W)
+
+
 class _PhotometricTrain(torch.autograd.Function):
     """All scales, forward and gradient, in one launch (csrc/photo_train.hip).  Returns (sums [nscales], idx_0..,
     depth0 or None, to_opt_0.. or None); keeps only the unit-upstream gradients for backward."""
@@ -233,55 +281,14 @@ class _PhotometricTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, target, invK, ident, cfg, noises, sources, nP, *tensors):
         # tensors = nP projection tensors (1: shared by the scales; nscales: one per scale) followed by the disparities
-        Pl, disps = tensors[:nP], tensors[nP:]
-        nsc = len(disps)
-        disps = [_f32c(x) for x in disps]
-        target, invK = _f32c(target), _f32c(invK)
-        sources = [_f32c(x) for x in sources]
-        per_scale_P = nP > 1
-        Ps = [_f32c(x) for x in Pl] if per_scale_P else [_f32c(Pl[0])] * nsc
-        B, _, H, W = target.shape
-        S = len(sources)
-        automask = cfg["automask"]
-        dev = target.device
-        d = _lib.make_train_desc(B, H, W, S, [tuple(x.shape[2:]) for x in disps], automask, cfg["min_depth"],
-                                 cfg["max_depth"], cfg.get("rows_per_chunk", 0))
-        src = _lib.make_sources(sources)
-        pre = cfg.get("pre")
-        if automask and pre is None:
-            ident = _f32c(ident)
-            noises = [_f32c(x) for x in noises]
-        idx = [torch.empty(B, H, W, device=dev, dtype=torch.uint8) for _ in range(nsc)]
-        sums = torch.empty(nsc, device=dev, dtype=torch.float32)
-        grads = cfg.get("grads", True)         # False: every scale's forward alone (validation / torch.no_grad())
-        gdisp = [torch.empty_like(x) for x in disps] if grads else None
-        gP = torch.empty(nsc, S, B, 3, 4, device=dev, dtype=torch.float32) if grads else None
-        depth0 = torch.empty(B, 1, H, W, device=dev, dtype=torch.float32) if cfg.get("need_depth") else None
-        to_opt = [torch.empty(B, H, W, device=dev, dtype=torch.float32) for _ in range(nsc)] \
-            if cfg.get("need_to_opt") else None
-        nws = lib().mdx_photometric_train_workspace_bytes(C.byref(d))
-        ws = torch.empty(nws // 16 + 1, 2, dtype=torch.float64, device=dev)
-        hook = _timing_hook("train" if grads else "eval")
-        tail = (_lib.ptr_array(idx, torch.uint8), ptr(sums), _lib.ptr_array(gdisp) if grads else None,
-                ptr(gP) if grads else None, ptr(depth0, optional=True),
-                _lib.ptr_array(to_opt) if to_opt is not None else None, ptr(ws, torch.float64), C.c_size_t(nws), stream(),
-                C.byref(hook) if hook is not None else None)
-        if pre is not None:
-            check(lib().mdx_photometric_train_pre(
-                C.byref(d), _lib.ptr_array(disps), ptr(target), C.byref(src), ptr(invK), _lib.ptr_array(Ps),
-                ptr(pre["tstat"]), _lib.ptr_array(pre["bidfi"]) if automask else None,
-                pre["rng"].ptr() if pre.get("rng") is not None else None, *tail), "mdx_photometric_train_pre")
-        else:
-            check(lib().mdx_photometric_train(
-                C.byref(d), _lib.ptr_array(disps), ptr(target), C.byref(src), ptr(invK), _lib.ptr_array(Ps),
-                ptr(ident) if automask else None, _lib.ptr_array(noises) if automask else None, *tail),
-                "mdx_photometric_train")
-        if grads:
-            ctx.save_for_backward(gP, *gdisp)
-        ctx.per_scale_P = per_scale_P
+        r = _train_launch(cfg, target, invK, ident, noises, sources, tensors[:nP], tensors[nP:])
+        idx, depth0, to_opt = r["idx"], r["depth0"], r["to_opt"]
+        if r["gP"] is not None:
+            ctx.save_for_backward(r["gP"], *r["gdisp"])
+        ctx.per_scale_P = r["per_scale_P"]
         extras = idx + [depth0] + (to_opt if to_opt is not None else [])
         ctx.mark_non_differentiable(*[t for t in extras if t is not None])
-        return (sums, *idx, depth0, *(to_opt if to_opt is not None else []))
+        return (r["sums"], *idx, depth0, *(to_opt if to_opt is not None else []))
 
     @staticmethod
     def backward(ctx, g_sums, *_unused):
@@ -348,24 +355,30 @@ def smooth_loss(disp, color, normalize=True):
     return _SmoothLoss.apply(disp, color, normalize)
 
 
+def _smooth_multi_launch(normalize, colors, disps, need):
+    """The two launches behind _SmoothLossMulti and _TrainLoss -> (loss [nscales], unit-upstream gradients or None)."""
+    disps = [_f32c(d) for d in disps]
+    colors = [_f32c(c) for c in colors]
+    n = len(disps)
+    B = disps[0].shape[0]
+    dev = disps[0].device
+    hs = (C.c_int32 * n)(*[int(d.shape[2]) for d in disps])
+    ws_ = (C.c_int32 * n)(*[int(d.shape[3]) for d in disps])
+    loss = torch.empty(n, device=dev, dtype=torch.float32)
+    gs = [torch.empty_like(d) for d in disps] if need else None
+    nws = lib().mdx_smooth_multi_workspace_bytes(n, B, hs, ws_)
+    ws = _ws(nws, dev)
+    check(lib().mdx_smooth_loss_multi(n, B, hs, ws_, _lib.ptr_array(disps), _lib.ptr_array(colors), int(normalize),
+                                      ptr(loss), _lib.ptr_array(gs) if need else None, ptr(ws, torch.float64),
+                                      C.c_size_t(nws), stream()), "mdx_smooth_loss_multi")
+    return loss, gs
+
+
 class _SmoothLossMulti(torch.autograd.Function):
     @staticmethod
     def forward(ctx, normalize, colors, *disps):
-        disps = [_f32c(d) for d in disps]
-        colors = [_f32c(c) for c in colors]
-        n = len(disps)
-        B = disps[0].shape[0]
-        dev = disps[0].device
-        hs = (C.c_int32 * n)(*[int(d.shape[2]) for d in disps])
-        ws_ = (C.c_int32 * n)(*[int(d.shape[3]) for d in disps])
-        loss = torch.empty(n, device=dev, dtype=torch.float32)
         need = any(ctx.needs_input_grad[2:])
-        gs = [torch.empty_like(d) for d in disps] if need else None
-        nws = lib().mdx_smooth_multi_workspace_bytes(n, B, hs, ws_)
-        ws = _ws(nws, dev)
-        check(lib().mdx_smooth_loss_multi(n, B, hs, ws_, _lib.ptr_array(disps), _lib.ptr_array(colors), int(normalize),
-                                          ptr(loss), _lib.ptr_array(gs) if need else None, ptr(ws, torch.float64),
-                                          C.c_size_t(nws), stream()), "mdx_smooth_loss_multi")
+        loss, gs = _smooth_multi_launch(normalize, colors, disps, need)
         if need:
             ctx.save_for_backward(*gs)
         return loss
@@ -380,6 +393,77 @@ def smooth_loss_multi(disps, colors, normalize=True):
     """SmoothLoss()(disp_s, color_s) for every scale of a step -> tensor [nscales]; each of the four passes is ONE
     launch for all scales (the per-scale op takes 16 launches per step)."""
     return _SmoothLossMulti.apply(bool(normalize), list(colors), *disps)
+
+
+class _TrainLoss(torch.autograd.Function):
+    """The whole loss of a training step (processor.py:163-217) as ONE autograd node: the smoothness launches, the training
+    kernel, one single-thread launch that finishes the scalar (csrc/loss_total.hip) -- and a backward of ONE launch that turns
+    the kernels' unit-upstream gradients into every scale's disparity gradient and the projection gradient."""
+
+    @staticmethod
+    def forward(ctx, target, invK, ident, cfg, noises, sources, colors, nP, *tensors):
+        Pl, disps = tensors[:nP], tensors[nP:]
+        nsc = len(disps)
+        grads = cfg.get("grads", True)
+        # the smoothness launches go BETWEEN the prologue and the training kernel (processor.compute_loss explains why)
+        smooth, gs = _smooth_multi_launch(True, colors, disps, grads)
+        r = _train_launch(cfg, target, invK, ident, noises, sources, Pl, disps)
+        total = torch.empty((), device=target.device, dtype=torch.float32)
+        scales = (C.c_int32 * nsc)(*[int(v) for v in cfg["scales"]])
+        check(lib().mdx_loss_total_fwd(nsc, ptr(r["sums"]), ptr(smooth), scales, C.c_int64(r["pixels"]),
+                                       C.c_double(cfg["disp_smoothness"]), ptr(total), stream()), "mdx_loss_total_fwd")
+        if grads:
+            ctx.save_for_backward(r["gP"], *r["gdisp"], *gs)
+        ctx.meta = (nsc, r["per_scale_P"], [int(v) for v in cfg["scales"]], r["pixels"], float(cfg["disp_smoothness"]),
+                    [t.dtype for t in disps], [t.dtype for t in Pl])
+        extras = [r["sums"], smooth] + r["idx"] + [r["depth0"]]
+        ctx.mark_non_differentiable(*[t for t in extras if t is not None])
+        return (total, r["sums"], smooth, *r["idx"], r["depth0"])
+
+    @staticmethod
+    def backward(ctx, g_total, *_unused):
+        nsc, per_scale_P, scale_ids, pixels, lam, ddt, pdt = ctx.meta
+        gP, *rest = ctx.saved_tensors
+        gd, gs = rest[:nsc], rest[nsc:]
+        g = _f32c(g_total).reshape(1)
+        out = [torch.empty_like(x) for x in gd]
+        nP = gP[0].numel()
+        need_P = any(ctx.needs_input_grad[8:8 + len(pdt)])
+        gP_out = (torch.empty_like(gP) if per_scale_P else torch.empty_like(gP[0])) if need_P else None
+        scales = (C.c_int32 * nsc)(*scale_ids)
+        counts = (C.c_int64 * nsc)(*[x.numel() for x in gd])
+        check(lib().mdx_loss_total_bwd(nsc, ptr(g), scales, C.c_int64(pixels), C.c_double(lam), _lib.ptr_array(gd),
+                                       _lib.ptr_array(gs), counts, _lib.ptr_array(out), ptr(gP) if need_P else None, nP,
+                                       int(per_scale_P), ptr(gP_out, optional=True), stream()), "mdx_loss_total_bwd")
+        if gP_out is None:
+            gPs = (None,) * len(pdt)
+        elif per_scale_P:
+            gPs = tuple(gP_out[s].to(pdt[s]) for s in range(nsc))
+        else:
+            gPs = (gP_out.to(pdt[0]),)
+        return (None,) * 8 + gPs + tuple(o.to(dt) for o, dt in zip(out, ddt))
+
+
+def train_loss(disps, P, target, sources, invK, colors, scales, disp_smoothness, ident=None, noises=None, automask=True,
+               min_depth=0.1, max_depth=100.0, need_depth=False, pre=None):
+    """outputs["loss"] of a training step (processor.py:163-217) from the disparities and the projections: smoothness
+    (smooth_loss_multi), photometric term (photometric_train) and the scalar tail, one autograd node.  colors: the target at
+    every scale; scales: opt.scales.  Returns dict: 'loss' (scalar, differentiable), 'sums', 'smooth' [nscales], 'idx', 'depth'.
+    The numbers are those of smooth_loss_multi + photometric_train + the reference's scalar ops, bit for bit (the projection
+    gradient: the scales are summed in index order)."""
+    Pl = list(P) if isinstance(P, (list, tuple)) else [P]
+    if len(Pl) not in (1, len(disps)):
+        raise _lib.MdxError("train_loss: %d projections for %d scales (one, or one per scale)" % (len(Pl), len(disps)))
+    if len(colors) != len(disps) or len(scales) != len(disps):
+        raise _lib.MdxError("train_loss: %d disparities, %d colour maps, %d scales" % (len(disps), len(colors), len(scales)))
+    grads = torch.is_grad_enabled() and any(t.requires_grad for t in list(disps) + Pl)
+    cfg = dict(automask=bool(automask), min_depth=float(min_depth), max_depth=float(max_depth), need_depth=bool(need_depth),
+               need_to_opt=False, rows_per_chunk=0, grads=grads, pre=pre, scales=[int(v) for v in scales],
+               disp_smoothness=float(disp_smoothness))
+    n = len(disps)
+    out = _TrainLoss.apply(target, invK, ident, cfg, list(noises) if noises is not None else None, list(sources),
+                           list(colors), len(Pl), *Pl, *disps)
+    return dict(loss=out[0], sums=out[1], smooth=out[2], idx=list(out[3:3 + n]), depth=out[3 + n])
 
 
 # ------------------------------------------------------------------------------------------------
@@ -870,6 +954,47 @@ def param2matrix(axisangle, translation, invert=False):
     """(axis-angle [N,1,3], translation [N,1,3]) -> camera-to-camera matrix [N,4,4] (reference warp.py:126-153) in
     one launch; backward by forward-mode differentiation inside the kernel."""
     return _Param2Matrix.apply(axisangle, translation, bool(invert))
+
+
+class _PoseProjection(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, raw, K, B, row0, frame, invert):
+        raw, K = _f32c(raw), _f32c(K)
+        M, F = raw.shape[0], raw.shape[1]
+        S = len(row0)
+        T = torch.empty(S, B, 4, 4, device=raw.device, dtype=torch.float32)
+        P = torch.empty(S, B, 3, 4, device=raw.device, dtype=torch.float32)
+        sel = tuple((C.c_int32 * S)(*[int(v) for v in a]) for a in (row0, frame, invert))
+        check(lib().mdx_pose_projection_fwd(ptr(raw), M, F, ptr(K), B, S, *sel, ptr(T), ptr(P), stream()),
+              "mdx_pose_projection_fwd")
+        ctx.save_for_backward(raw, K)
+        ctx.meta = (B, [int(v) for v in row0], [int(v) for v in frame], [int(v) for v in invert])
+        return T, P
+
+    @staticmethod
+    def backward(ctx, gT, gP):
+        raw, K = ctx.saved_tensors
+        B, row0, frame, invert = ctx.meta
+        M, F = raw.shape[0], raw.shape[1]
+        S = len(row0)
+        graw = torch.empty_like(raw)
+        sel = tuple((C.c_int32 * S)(*a) for a in (row0, frame, invert))
+        check(lib().mdx_pose_projection_bwd(ptr(raw), M, F, ptr(K), B, S, *sel,
+                                            ptr(_f32c(gP)) if gP is not None else None,
+                                            ptr(_f32c(gT)) if gT is not None else None, ptr(graw), stream()),
+              "mdx_pose_projection_bwd")
+        return graw, None, None, None, None, None
+
+
+def pose_projection(raw, K, row0, frame, invert):
+    """The pose head's output -> (T [S,B,4,4], P [S,B,3,4]) for every source frame in one launch (and one backward):
+    raw [M,F,1,6] or [M,F,6] (axis-angle | translation, pose_decoder.py:51-53); source s takes rows row0[s]..row0[s]+B-1, entry
+    frame[s], inverted if invert[s] (processor.py:61-83); P = (K @ T)[:, :3] (processor.py:143-160).  B = K.shape[0].
+    The numbers are those of the slices + param2matrix + compose_projection."""
+    if K.requires_grad:
+        raise _lib.MdxError("pose_projection: K must not require a gradient (use param2matrix + compose_projection)")
+    B = K.shape[0]
+    return _PoseProjection.apply(raw.reshape(raw.shape[0], raw.shape[1], 6), K, B, list(row0), list(frame), list(invert))
 
 
 # ---- train-time depth monitor (csrc/monitor.hip) -------------------------------------------------------------------

@@ -70,6 +70,9 @@ class compute(object):
         # False: round 2's form (identity kernel + torch.randn + the training kernel re-deriving the target statistics
         # per scale) -- kept for A/B measurements (bench.py --no-prologue)
         self.prologue = _opt(opt, "prologue", True)
+        # False: the step's small ops as the reference spells them -- the scalar tail of the loss as ~5 torch ops per scale, the
+        # pose head's output sliced per frame into param2matrix + K @ T (A/B and parity tests; same numbers)
+        self.fused_tail = self.fused and _opt(opt, "fused_tail", True)
 
     # -- networks ---------------------------------------------------------------------------------
     def _autocast(self):
@@ -186,9 +189,22 @@ class compute(object):
             feats = setting.model["pose_encoder"](torch.cat(pairs, 0))
         axisangle, translation = setting.model["pose_decoder"]([feats])
         for k, frame_id in enumerate(frames):
-            aa, tr = axisangle[k * n:(k + 1) * n], translation[k * n:(k + 1) * n]
-            outputs[("R", frame_id, 0)] = aa
-            outputs[("T", frame_id, 0)] = tr
+            outputs[("R", frame_id, 0)] = axisangle[k * n:(k + 1) * n]
+            outputs[("T", frame_id, 0)] = translation[k * n:(k + 1) * n]
+        raw = axisangle._base if axisangle._base is not None and axisangle._base is translation._base else None
+        K = inputs[("K", 0)]
+        if (self.fused_tail and raw is not None and raw.is_cuda and raw.dim() == 4 and raw.shape[-1] == 6 and raw.is_contiguous()
+                and frames == list(opt.frame_ids[1:]) and not K.requires_grad):
+            # every source frame's matrix AND projection from the pose head's output in one launch (one in backward): the
+            # reference's row slice + [:, 0] + param2matrix + K @ T per frame is ~10 launches forward and ~30 backward
+            T, P = F.pose_projection(raw.float(), K, [k * n for k in range(len(frames))], [0] * len(frames),
+                                     [int(f < 0) for f in frames])
+            for k, frame_id in enumerate(frames):
+                outputs[("c2c", frame_id, 0)] = T[k]
+            outputs[("P", "pose_head")] = P
+            return
+        for k, frame_id in enumerate(frames):
+            aa, tr = outputs[("R", frame_id, 0)], outputs[("T", frame_id, 0)]
             outputs[("c2c", frame_id, 0)] = param2matrix(axisangle=aa[:, 0].float(), translation=tr[:, 0].float(),
                                                          invert=(frame_id < 0))
 
@@ -212,6 +228,11 @@ class compute(object):
     def image2warping(self, inputs, outputs, setting):
         opt = self.opt
         K = inputs[("K", 0)]
+        if self.fused and ("P", "pose_head") in outputs:      # forward_pose formed the projections with the matrices
+            P = outputs.pop(("P", "pose_head"))
+            for s in opt.scales:
+                outputs[("P", s)] = P
+            return inputs, outputs
         for scale in opt.scales:
             depth = None
             if not self.fused:
@@ -305,6 +326,22 @@ class compute(object):
             # The smoothness launches go BETWEEN the prologue and the training kernel (they depend on neither).  Launched right
             # behind the prologue -- which writes 80 MB in 44 us -- the training kernel runs 17 % longer (223 us against 190 us,
             # same code, same data: profiles/r04_load_latency.txt); two short launches in between and it does not.
+            if self.fused_tail and target.is_cuda:
+                # smoothness, photometric term and the scalar tail of processor.py:208-217 as one autograd node: one launch
+                # finishes the scalar, one launch in backward writes every scale's disparity gradient (mdx/functional.py: _TrainLoss)
+                res = F.train_loss([outputs[("disp", s)].float() for s in opt.scales],
+                                   (outputs[("P", opt.scales[0])] if opt.pose_type != "posecnn"
+                                    else [outputs[("P", s)] for s in opt.scales]),
+                                   target, sources, inputs[("inv_K", 0)], [inputs[("color", 0, s)] for s in opt.scales],
+                                   opt.scales, opt.disp_smoothness, ident, noises if pre is None else None,
+                                   automask=automask, min_depth=opt.min_depth, max_depth=opt.max_depth,
+                                   need_depth=(opt.scales[0] == 0), pre=pre)
+                if res["depth"] is not None:
+                    outputs[("depth", 0, 0)] = res["depth"]
+                for k, scale in enumerate(opt.scales):
+                    outputs[("automask", scale)] = res["idx"][k]
+                outputs["loss"] = res["loss"]
+                return outputs
             if self.fused and target.is_cuda:
                 smooth_all = F.smooth_loss_multi([outputs[("disp", s)].float() for s in opt.scales],
                                                  [inputs[("color", 0, s)] for s in opt.scales])

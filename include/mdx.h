@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MDX_VERSION 500
+#define MDX_VERSION 510
 #define MDX_MAX_SRC 4
 #define MDX_MAX_SCALES 4
 
@@ -216,6 +216,19 @@ int mdx_smooth_loss_multi(int nscales, int B, const int32_t *h, const int32_t *w
                           const float *const *color, int normalize, float *loss, float *const *gdisp,
                           void *workspace, size_t workspace_bytes, void *stream);
 
+/* The scalar tail of the loss   processor.py:208-217 (scale_loss = mean + disp_smoothness * smooth / 2**scale; total = sum / len)
+ * and its backward fan-out, one launch each way instead of ~20 / ~30 scalar launches + three whole-map passes per scale.
+ * sums [nscales] = sum over the pixels of to_optimise (mdx_photometric_train), smooth [nscales] (mdx_smooth_loss_multi),
+ * scale: HOST array opt.scales, pixels = B*H*W -> total [1].  Rounded op by op as ATen-GPU rounds the reference's expression.
+ * bwd: g_total [1] (device), gd_photo / gd_smooth: HOST arrays of nscales device pointers (the unit-upstream gradients the two
+ * kernels left), count[s] = elements of scale s -> gdisp[s] = gd_photo[s] * c1 + gd_smooth[s] * c2[s];
+ * gP [nscales][nP] (optional) -> gP_out [nscales][nP] * c1 (per_scale_P) or their sum over the scales [nP]. */
+int mdx_loss_total_fwd(int nscales, const float *sums, const float *smooth, const int32_t *scale, int64_t pixels,
+                       double disp_smoothness, float *total, void *stream);
+int mdx_loss_total_bwd(int nscales, const float *g_total, const int32_t *scale, int64_t pixels, double disp_smoothness,
+                       const float *const *gd_photo, const float *const *gd_smooth, const int64_t *count,
+                       float *const *gdisp, const float *gP, int nP, int per_scale_P, float *gP_out, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Fine-grained ops behind the reference's model_layer / model_loss API (each differentiable)
  * ---------------------------------------------------------------------------------------- */
@@ -279,6 +292,17 @@ int mdx_min_automask_fwd(const float *ident, const float *noise, const float *re
 int mdx_param2matrix_fwd(const float *axisangle, const float *translation, int N, int invert, float *M, void *stream);
 int mdx_param2matrix_bwd(const float *axisangle, const float *translation, const float *gM, int N, int invert,
                          float *gaxisangle, float *gtranslation, void *stream);
+
+/* The pose network's output -> camera-to-camera matrices and projections for every source frame, one launch each way
+ * (processor.py:61-83 slices + param2matrix, :143-160 K @ T): raw [M,F,6] = the pose head's 0.01-scaled output
+ * (axis-angle | translation; pose_decoder.py:51-53); source s reads rows row0[s] .. row0[s]+B-1, entry frame[s], inverted if
+ * invert[s] (HOST arrays of S entries); K [B,4,4] -> T [S,B,4,4], P [S,B,3,4] = (K @ T)[:, :3].
+ * bwd: gP [S,B,3,4] and / or gT [S,B,4,4] (either may be NULL) -> graw [M,F,6] (entries no source reads: zeros). */
+int mdx_pose_projection_fwd(const float *raw, int M, int F, const float *K, int B, int S, const int32_t *row0,
+                            const int32_t *frame, const int32_t *invert, float *T, float *P, void *stream);
+int mdx_pose_projection_bwd(const float *raw, int M, int F, const float *K, int B, int S, const int32_t *row0,
+                            const int32_t *frame, const int32_t *invert, const float *gP, const float *gT, float *graw,
+                            void *stream);
 
 /* ---- network glue around the convolutions (no reference FFI: these replace torch op sequences of
  * model_layer/depth_decoder.py:44-47,96-106 and the ResNet stem max-pool, model_layer/depth_encoder.py) ----

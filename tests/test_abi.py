@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.lib()
     for name in header_functions():
         assert hasattr(lib, name), name
-    assert lib.mdx_version() == 500
+    assert lib.mdx_version() == 510
     assert lib.mdx_status_string(0) == b"MDX_OK"
     assert lib.mdx_status_string(-3) == b"MDX_ERR_WORKSPACE"
 

@@ -20,14 +20,14 @@ def G():
     return gpu_util
 
 
-def _setup(G, c, fused, fused_train=True):
+def _setup(G, c, fused, fused_train=True, fused_tail=True):
     from model_tool.processor import compute
     from model_layer import Depth2PointCloud, PointCloud2Pixel
     from model_loss import ReprojectionLoss, SmoothLoss
     opt = types.SimpleNamespace(scales=list(range(c.n_scales)), frame_ids=c.frame_ids, height=c.H, width=c.W,
                                 min_depth=0.1, max_depth=100.0, disp_smoothness=1e-3, use_automasking=c.automask,
                                 batch=c.B, pose_type="separate", pose_frames="pair", fused=fused, noise="device",
-                                fused_train=fused_train)
+                                fused_train=fused_train, fused_tail=fused_tail)
     st = types.SimpleNamespace(inv_projection={0: Depth2PointCloud(c.B, c.H, c.W)},
                                for_projection={0: PointCloud2Pixel(c.B, c.H, c.W)},
                                loss={"reprojection": ReprojectionLoss(), "edge_aware": SmoothLoss()})
@@ -48,12 +48,15 @@ def _setup(G, c, fused, fused_train=True):
     return compute(opt, G.DEV), st, inputs, outputs
 
 
-@pytest.mark.parametrize("mode", ["train_kernel", "per_scale", "op_by_op"])
+@pytest.mark.parametrize("mode", ["train_kernel", "train_kernel_scalar_ops", "per_scale", "op_by_op"])
 @pytest.mark.parametrize("name", goldens.CASES)
 def test_compute_driver_vs_golden(G, name, mode):
+    """train_kernel: the step's default (one autograd node for the whole loss, mdx.functional.train_loss);
+    train_kernel_scalar_ops: the same kernels with the reference's scalar ops after them (opt.fused_tail = False)."""
     c = goldens.Case(name)
     fused = mode != "op_by_op"
-    cp, st, inputs, outputs = _setup(G, c, fused, fused_train=(mode == "train_kernel"))
+    cp, st, inputs, outputs = _setup(G, c, fused, fused_train=mode.startswith("train_kernel"),
+                                     fused_tail=(mode == "train_kernel"))
     inputs, outputs = cp.image2warping(inputs, outputs, st)
     outputs = cp.compute_loss(inputs, outputs, st)
     outputs["loss"].backward()
@@ -69,6 +72,65 @@ def test_compute_driver_vs_golden(G, name, mode):
     if not fused and ("warp_%s_s0" % c.sources_ids[0]) in c:
         for f in c.sources_ids:
             G.assert_bitexact(outputs[("warp_color", f, 0)], c["warp_%s_s0" % f], "warp_color %s" % f)
+
+
+@pytest.mark.parametrize("name", goldens.CASES)
+def test_loss_tail_one_node_equals_scalar_ops(G, name):
+    """mdx.functional.train_loss (one launch finishes the scalar, one launch fans the gradient out) against the reference's
+    scalar ops behind the same kernels: loss and disparity gradients bit for bit, matrix gradients to rounding (the scales'
+    projection gradients are summed in index order instead of by ATen's reduction)."""
+    c = goldens.Case(name)
+    res = []
+    for tail in (True, False):
+        cp, st, inputs, outputs = _setup(G, c, True, fused_train=True, fused_tail=tail)
+        inputs, outputs = cp.image2warping(inputs, outputs, st)
+        outputs = cp.compute_loss(inputs, outputs, st)
+        (outputs["loss"] * 1.7).backward()                 # an upstream gradient that is not 1
+        res.append(outputs)
+    a, b = res
+    assert torch.equal(a["loss"], b["loss"]), (float(a["loss"]), float(b["loss"]))
+    for s in range(c.n_scales):
+        assert torch.equal(a[("disp", s)].grad, b[("disp", s)].grad), "grad disp s%d" % s
+        assert torch.equal(a[("automask", s)], b[("automask", s)])
+    for f in c.sources_ids:
+        if f != "s":
+            ga, gb = a[("c2c", f, 0)].grad, b[("c2c", f, 0)].grad
+            assert float((ga - gb).abs().max()) <= 2e-6 * float(gb.abs().max()) + 1e-12, "grad T %s" % f
+    assert torch.equal(a[("depth", 0, 0)], b[("depth", 0, 0)])
+
+
+def test_pose_projection_equals_slices_param2matrix_compose(G):
+    """mdx.functional.pose_projection (the pose head's output -> matrices and projections of both source frames, one launch each
+    way) against the reference's row slice + [:, 0] + param2matrix + K @ T per frame (processor.py:61-83, :143-160)."""
+    from mdx import functional as F
+    g = torch.Generator().manual_seed(5)
+    n, Fr = 5, 2
+    base = (0.05 * torch.randn(2 * n, Fr, 1, 6, generator=g)).to(G.DEV)
+    K = torch.eye(4).repeat(n, 1, 1)
+    K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2] = 0.58 * 64, 1.92 * 32, 32.0, 16.0
+    K = K.to(G.DEV)
+    wP = torch.randn(2, n, 3, 4, generator=g).to(G.DEV)
+    wT = torch.randn(2, n, 4, 4, generator=g).to(G.DEV)
+    for frame in (0, 1):
+        for with_T in (False, True):
+            raw1 = base.clone().requires_grad_(True)
+            T1, P1 = F.pose_projection(raw1, K, [0, n], [frame, frame], [1, 0])
+            ((P1 * wP).sum() + ((T1 * wT).sum() if with_T else 0.0)).backward()
+            raw2 = base.clone().requires_grad_(True)
+            aa, tr = raw2[..., :3], raw2[..., 3:]
+            Ts, Ps = [], []
+            for k, inv in enumerate((True, False)):
+                a, t = aa[k * n:(k + 1) * n], tr[k * n:(k + 1) * n]
+                Ts.append(F.param2matrix(a[:, frame].float(), t[:, frame].float(), invert=inv))
+                Ps.append(F.compose_projection(K, Ts[-1]))
+            T2, P2 = torch.stack(Ts), torch.stack(Ps)
+            ((P2 * wP).sum() + ((T2 * wT).sum() if with_T else 0.0)).backward()
+            assert torch.equal(T1, T2) and torch.equal(P1, P2)
+            d = float((raw1.grad - raw2.grad).abs().max())
+            assert d <= 2e-6 * float(raw2.grad.abs().max()), (frame, with_T, d)
+            assert float(raw1.grad[:, 1 - frame].abs().max()) == 0.0        # the entry no source reads
+    with pytest.raises(Exception):
+        F.pose_projection(base, K, [0, n + 1], [0, 0], [1, 0])              # rows beyond the head's output
 
 
 def test_training_step_runs_and_learns(G):

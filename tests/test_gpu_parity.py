@@ -31,7 +31,7 @@ def _P(G, c):
 
 def test_library_loaded(G):
     from mdx import lib, LIB_PATH
-    assert lib().mdx_version() == 500
+    assert lib().mdx_version() == 510
     assert LIB_PATH.endswith("libmdx_hip.so")
 
 

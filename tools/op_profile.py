@@ -25,7 +25,8 @@ def main():
     ap.add_argument("--amp", default="none")
     ap.add_argument("--channels-last", default="auto")
     ap.add_argument("--top", type=int, default=40)
-    ap.add_argument("--filter", default="", help="only ops whose name contains this (e.g. copy_)")
+    ap.add_argument("--filter", default="", help="only ops whose name contains one of these, comma separated (e.g. copy_,fill_)")
+    ap.add_argument("--stack", type=int, default=0, help="group by the innermost N Python frames too and print them")
     a = ap.parse_args()
     bench = importlib.import_module("bench")
     from model_train import trainer
@@ -39,17 +40,19 @@ def main():
         tr._eager_step(inputs)
     torch.cuda.synchronize()
     from torch.profiler import ProfilerActivity, profile
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=a.stack > 0) as prof:
         for _ in range(2):
             tr._eager_step(inputs)
         torch.cuda.synchronize()
     rows = []
-    for e in prof.key_averages(group_by_input_shape=True):
+    wanted = [w for w in a.filter.split(",") if w]
+    for e in prof.key_averages(group_by_input_shape=True, group_by_stack_n=a.stack):
         t = getattr(e, "self_device_time_total", None)
         if t is None:
             t = getattr(e, "self_cuda_time_total", 0)
-        if t > 0 and a.filter in e.key:
-            rows.append((t / 2e3, e.count // 2, e.key, str(e.input_shapes)[:150]))
+        if t > 0 and (not wanted or any(w in e.key for w in wanted)):
+            where = " <- ".join(f.split("/")[-1] for f in (e.stack or []) if ".py" in f)[:300] if a.stack else ""
+            rows.append((t / 2e3, e.count // 2, e.key, str(e.input_shapes)[:150] + ("   @ " + where if where else "")))
     rows.sort(reverse=True)
     print("%9s %6s  %-44s %s" % ("ms/step", "calls", "op", "input shapes"))
     for t, n, k, s in rows[:a.top]:
