@@ -271,6 +271,7 @@ __global__ __launch_bounds__(NB) void bn_nhwc_fwd_apply_kernel(const T *__restri
 template <typename T>
 __global__ __launch_bounds__(NB) void bn_nhwc_bwd_stats_kernel(const T *__restrict__ dy, const T *__restrict__ dy2,
                                                                const T *__restrict__ y, const T *__restrict__ x,
+                                                               const float *__restrict__ gamma, const float *__restrict__ beta,
                                                                const float *__restrict__ save_mean,
                                                                const float *__restrict__ save_invstd, int M, int C, int CVB, int PL,
                                                                int RB, int relu, float *__restrict__ part)
@@ -282,20 +283,26 @@ __global__ __launch_bounds__(NB) void bn_nhwc_bwd_stats_kernel(const T *__restri
 #pragma unroll
     for (int j = 0; j < N; ++j) a[j] = q[j] = 0.f;
     if (p.active) {
-        float mean[N], invstd[N];
+        float mean[N], invstd[N], scale[N], shift[N];
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             mean[j] = save_mean[(size_t)p.g * C + p.cv * N + j];
             invstd[j] = save_invstd[(size_t)p.g * C + p.cv * N + j];
+            scale[j] = shift[j] = 0.f;
+            if (!y && relu) {          // the forward pass's own expressions (bn_nhwc_fwd_apply_kernel): y is re-derived, not read
+                scale[j] = gamma[p.cv * N + j] * invstd[j];
+                shift[j] = beta[p.cv * N + j] - mean[j] * scale[j];
+            }
         }
         const size_t base = (size_t)p.g * M * C + (size_t)p.cv * N;
-        const T *pd = dy + base, *pd2 = dy2 ? dy2 + base : nullptr, *py = y + base, *px = x + base;
+        const T *pd = dy + base, *pd2 = dy2 ? dy2 + base : nullptr, *py = y ? y + base : nullptr, *px = x + base;
         auto acc = [&](const Vec<T, N> &vd, const Vec<T, N> &vd2, const Vec<T, N> &vy, const Vec<T, N> &vx) {
 #pragma unroll
             for (int j = 0; j < N; ++j) {
                 float d = to_float(vd.v[j]);
                 if (pd2) d += to_float(vd2.v[j]);
-                const float dz = (relu && !(to_float(vy.v[j]) > 0.f)) ? 0.f : d;
+                const float yv = py ? to_float(vy.v[j]) : to_float(from_float<T>(__builtin_fmaf(to_float(vx.v[j]), scale[j], shift[j])));
+                const float dz = (relu && !(yv > 0.f)) ? 0.f : d;
                 a[j] += dz;
                 q[j] = __builtin_fmaf(dz, (to_float(vx.v[j]) - mean[j]) * invstd[j], q[j]);
             }
@@ -304,7 +311,8 @@ __global__ __launch_bounds__(NB) void bn_nhwc_bwd_stats_kernel(const T *__restri
         for (; r + PL < p.r1; r += 2 * PL) {
             const size_t o0 = (size_t)r * C, o1 = (size_t)(r + PL) * C;
             const Vec<T, N> d0 = load_vec<T, N>(pd + o0), d1 = load_vec<T, N>(pd + o1);
-            const Vec<T, N> y0 = load_vec<T, N>(py + o0), y1 = load_vec<T, N>(py + o1);
+            Vec<T, N> y0 = {}, y1 = {};
+            if (py) { y0 = load_vec<T, N>(py + o0); y1 = load_vec<T, N>(py + o1); }
             const Vec<T, N> x0 = load_vec<T, N>(px + o0), x1 = load_vec<T, N>(px + o1);
             Vec<T, N> e0 = {}, e1 = {};
             if (pd2) { e0 = load_vec<T, N>(pd2 + o0); e1 = load_vec<T, N>(pd2 + o1); }
@@ -313,9 +321,10 @@ __global__ __launch_bounds__(NB) void bn_nhwc_bwd_stats_kernel(const T *__restri
         }
         for (; r < p.r1; r += PL) {
             const size_t o = (size_t)r * C;
-            Vec<T, N> e = {};
+            Vec<T, N> e = {}, yv = {};
             if (pd2) e = load_vec<T, N>(pd2 + o);
-            acc(load_vec<T, N>(pd + o), e, load_vec<T, N>(py + o), load_vec<T, N>(px + o));
+            if (py) yv = load_vec<T, N>(py + o);
+            acc(load_vec<T, N>(pd + o), e, yv, load_vec<T, N>(px + o));
         }
     }
     block_partials<N>(a, q, lds, CVB, PL, C, part + ((size_t)p.g * gridDim.x + blockIdx.x) * 2 * C);
@@ -325,7 +334,8 @@ __global__ __launch_bounds__(NB) void bn_nhwc_bwd_stats_kernel(const T *__restri
 template <typename T>
 __global__ __launch_bounds__(NB) void bn_nhwc_bwd_apply_kernel(const T *__restrict__ dy, const T *__restrict__ dy2,
                                                                const T *__restrict__ y, const T *__restrict__ x,
-                                                               const float *__restrict__ gamma, const float *__restrict__ save_mean,
+                                                               const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                               const float *__restrict__ save_mean,
                                                                const float *__restrict__ save_invstd,
                                                                const float *__restrict__ totals, int M, int C, int CVB, int PL,
                                                                int RB, int relu, T *__restrict__ dx, T *__restrict__ dres)
@@ -333,18 +343,19 @@ __global__ __launch_bounds__(NB) void bn_nhwc_bwd_apply_kernel(const T *__restri
     constexpr int N = VecN<T>::N;
     const Pos p = position<N>(M, C, CVB, PL, RB);
     if (!p.active) return;
-    float mean[N], invstd[N], k0[N], mdz[N], mdzx[N];
+    float mean[N], invstd[N], k0[N], mdz[N], mdzx[N], shift[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) {
         const int c = p.cv * N + j;
         mean[j] = save_mean[(size_t)p.g * C + c];
         invstd[j] = save_invstd[(size_t)p.g * C + c];
-        k0[j] = gamma[c] * invstd[j];
+        k0[j] = gamma[c] * invstd[j];                      // = the forward pass's scale
+        shift[j] = (!y && relu) ? beta[c] - mean[j] * k0[j] : 0.f;
         mdz[j] = (float)((double)totals[((size_t)p.g * 2 + 0) * C + c] / (double)M);
         mdzx[j] = (float)((double)totals[((size_t)p.g * 2 + 1) * C + c] / (double)M);
     }
     const size_t base = (size_t)p.g * M * C + (size_t)p.cv * N;
-    const T *pd = dy + base, *pd2 = dy2 ? dy2 + base : nullptr, *py = y + base, *px = x + base;
+    const T *pd = dy + base, *pd2 = dy2 ? dy2 + base : nullptr, *py = y ? y + base : nullptr, *px = x + base;
     T *ox = dx + base;
     T *orr = dres ? dres + base : nullptr;
     auto apply = [&](const Vec<T, N> &vd, const Vec<T, N> &vd2, const Vec<T, N> &vy, const Vec<T, N> &vx, size_t off) {
@@ -353,7 +364,8 @@ __global__ __launch_bounds__(NB) void bn_nhwc_bwd_apply_kernel(const T *__restri
         for (int j = 0; j < N; ++j) {
             float d = to_float(vd.v[j]);
             if (pd2) d += to_float(vd2.v[j]);
-            const float dz = (relu && !(to_float(vy.v[j]) > 0.f)) ? 0.f : d;
+            const float yv = py ? to_float(vy.v[j]) : to_float(from_float<T>(__builtin_fmaf(to_float(vx.v[j]), k0[j], shift[j])));
+            const float dz = (relu && !(yv > 0.f)) ? 0.f : d;
             const float xh = (to_float(vx.v[j]) - mean[j]) * invstd[j];
             wx.v[j] = from_float<T>(k0[j] * (dz - mdz[j] - xh * mdzx[j]));
             wr.v[j] = from_float<T>(dz);
@@ -365,7 +377,8 @@ __global__ __launch_bounds__(NB) void bn_nhwc_bwd_apply_kernel(const T *__restri
     for (; r + PL < p.r1; r += 2 * PL) {
         const size_t o0 = (size_t)r * C, o1 = (size_t)(r + PL) * C;
         const Vec<T, N> d0 = load_vec<T, N>(pd + o0), d1 = load_vec<T, N>(pd + o1);
-        const Vec<T, N> y0 = load_vec<T, N>(py + o0), y1 = load_vec<T, N>(py + o1);
+        Vec<T, N> y0 = {}, y1 = {};
+        if (py) { y0 = load_vec<T, N>(py + o0); y1 = load_vec<T, N>(py + o1); }
         const Vec<T, N> x0 = load_vec<T, N>(px + o0), x1 = load_vec<T, N>(px + o1);
         Vec<T, N> e0 = {}, e1 = {};
         if (pd2) { e0 = load_vec<T, N>(pd2 + o0); e1 = load_vec<T, N>(pd2 + o1); }
@@ -374,9 +387,10 @@ __global__ __launch_bounds__(NB) void bn_nhwc_bwd_apply_kernel(const T *__restri
     }
     for (; r < p.r1; r += PL) {
         const size_t o = (size_t)r * C;
-        Vec<T, N> e = {};
+        Vec<T, N> e = {}, yv = {};
         if (pd2) e = load_vec<T, N>(pd2 + o);
-        apply(load_vec<T, N>(pd + o), e, load_vec<T, N>(py + o), load_vec<T, N>(px + o), o);
+        if (py) yv = load_vec<T, N>(py + o);
+        apply(load_vec<T, N>(pd + o), e, yv, load_vec<T, N>(px + o), o);
     }
 }
 
@@ -439,16 +453,19 @@ MDX_EXPORT int mdx_bn_act_nhwc_fwd(const void *x, const void *res, const float *
 }
 
 // dy2 (optional): a second upstream gradient of y, added on the way in.  dres (optional): gradient of the residual input.
+// y NULL (relu, no residual, beta given): the ReLU mask is re-derived from x with the forward pass's own expressions instead of
+// being read -- one map less in each of the two passes.
 MDX_EXPORT int mdx_bn_act_nhwc_bwd(const void *dy, const void *dy2, const void *y, const void *x, const float *gamma,
-                                   const float *save_mean, const float *save_invstd, void *dx, void *dres, float *dgamma,
+                                   const float *beta, const float *save_mean, const float *save_invstd, void *dx, void *dres, float *dgamma,
                                    float *dbeta, int B, int C, int H, int W, int groups, int relu, int dtype, void *workspace,
                                    size_t workspace_bytes, void *stream)
 {
-    if (!dy || !y || !x || !gamma || !save_mean || !save_invstd || !dx || !dgamma || !dbeta || !workspace)
+    if (!dy || !x || !gamma || !save_mean || !save_invstd || !dx || !dgamma || !dbeta || !workspace)
         return MDX_ERR_NULL_POINTER;
+    if (!y && relu && (!beta || dres)) return MDX_ERR_NULL_POINTER;     // without y the mask needs beta, and there is no residual
     const int bad = nhwc_args_ok(B, C, H, W, groups, dtype);
     if (bad) return bad;
-    if (!aligned(dy, 16) || !aligned(y, 16) || !aligned(x, 16) || !aligned(dx, 16) || (dy2 && !aligned(dy2, 16)) ||
+    if (!aligned(dy, 16) || (y && !aligned(y, 16)) || !aligned(x, 16) || !aligned(dx, 16) || (dy2 && !aligned(dy2, 16)) ||
         (dres && !aligned(dres, 16)))
         return MDX_ERR_MISALIGNED;
     if (workspace_bytes < mdx_bn_nhwc_workspace_bytes(B, C, H, W, groups, dtype)) return MDX_ERR_WORKSPACE;
@@ -460,19 +477,19 @@ MDX_EXPORT int mdx_bn_act_nhwc_bwd(const void *dy, const void *dy2, const void *
     const dim3 grid_s(gs.nblk, gs.t.ny, groups), grid_a(ga.nblk, ga.t.ny, groups), block(NB);
     if (dtype == 0)
         hipLaunchKernelGGL((bn_nhwc_bwd_stats_kernel<float>), grid_s, block, 0, st, (const float *)dy, (const float *)dy2,
-                           (const float *)y, (const float *)x, save_mean, save_invstd, M, C, gs.t.CVB, gs.t.PL, gs.RB, relu, part);
+                           (const float *)y, (const float *)x, gamma, beta, save_mean, save_invstd, M, C, gs.t.CVB, gs.t.PL, gs.RB, relu, part);
     else
         hipLaunchKernelGGL((bn_nhwc_bwd_stats_kernel<bf16>), grid_s, block, 0, st, (const bf16 *)dy, (const bf16 *)dy2,
-                           (const bf16 *)y, (const bf16 *)x, save_mean, save_invstd, M, C, gs.t.CVB, gs.t.PL, gs.RB, relu, part);
+                           (const bf16 *)y, (const bf16 *)x, gamma, beta, save_mean, save_invstd, M, C, gs.t.CVB, gs.t.PL, gs.RB, relu, part);
     hipLaunchKernelGGL(bn_nhwc_bwd_finalize_kernel, dim3((C + FC - 1) / FC), dim3(FC * FS), 0, st, part, gs.nblk, C, groups, totals,
                        dgamma, dbeta);
     if (dtype == 0)
         hipLaunchKernelGGL((bn_nhwc_bwd_apply_kernel<float>), grid_a, block, 0, st, (const float *)dy, (const float *)dy2,
-                           (const float *)y, (const float *)x, gamma, save_mean, save_invstd, totals, M, C, ga.t.CVB, ga.t.PL, ga.RB,
+                           (const float *)y, (const float *)x, gamma, beta, save_mean, save_invstd, totals, M, C, ga.t.CVB, ga.t.PL, ga.RB,
                            relu, (float *)dx, (float *)dres);
     else
         hipLaunchKernelGGL((bn_nhwc_bwd_apply_kernel<bf16>), grid_a, block, 0, st, (const bf16 *)dy, (const bf16 *)dy2,
-                           (const bf16 *)y, (const bf16 *)x, gamma, save_mean, save_invstd, totals, M, C, ga.t.CVB, ga.t.PL, ga.RB,
+                           (const bf16 *)y, (const bf16 *)x, gamma, beta, save_mean, save_invstd, totals, M, C, ga.t.CVB, ga.t.PL, ga.RB,
                            relu, (bf16 *)dx, (bf16 *)dres);
     return check_launch();
 }

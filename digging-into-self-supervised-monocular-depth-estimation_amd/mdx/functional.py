@@ -873,8 +873,11 @@ class _BnAct(torch.autograd.Function):
                  ptr(running_var) if running_var is not None else None, ptr(y, x.dtype, cl=cl), ptr(save_mean),
                  ptr(save_invstd), Bg, Cc, H, W, groups, C.c_float(eps), C.c_float(momentum), int(relu), code, ptr(ws),
                  C.c_size_t(nws), stream()), "mdx_bn_act_fwd")
-        ctx.save_for_backward(x, y, weight, save_mean, save_invstd)
-        ctx.meta = (bool(relu), res is not None, groups, cl)
+        # channels-last float32, ReLU, no residual: backward re-derives the ReLU mask from x (y is not read: one map less per pass;
+        # 760.3 -> 765.4 images/s.  bfloat16 maps: 1498 -> 1492 -- the re-derivation costs more than half a map of traffic)
+        mask_from_x = cl and bool(relu) and res is None and x.dtype == torch.float32
+        ctx.save_for_backward(x, bias if mask_from_x else y, weight, save_mean, save_invstd)
+        ctx.meta = (bool(relu), res is not None, groups, cl, mask_from_x)
         ctx.mark_non_differentiable(*[t for t in (running_mean, running_var) if t is not None])
         ctx.set_materialize_grads(False)
         return (y, y.view_as(y)) if fork else y
@@ -882,7 +885,10 @@ class _BnAct(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, dy2=None):
         x, y, weight, save_mean, save_invstd = ctx.saved_tensors
-        relu, has_res, groups, cl = ctx.meta
+        relu, has_res, groups, cl, mask_from_x = ctx.meta
+        bias = None
+        if mask_from_x:
+            y, bias = None, y
         none = (None,) * 11
         dy, dy2 = _two_grads(dy, dy2, x.dtype, cl, fused_add=cl)
         if dy is None:
@@ -898,8 +904,9 @@ class _BnAct(torch.autograd.Function):
             nws = lib().mdx_bn_nhwc_workspace_bytes(Bg, Cc, H, W, groups, code)
             ws = torch.empty(nws // 4 + 1, device=x.device, dtype=torch.float32)
             check(lib().mdx_bn_act_nhwc_bwd(
-                ptr(dy, x.dtype, cl=True), ptr(dy2, x.dtype, cl=True) if dy2 is not None else None, ptr(y, x.dtype, cl=True),
-                ptr(x, x.dtype, cl=True), ptr(weight), ptr(save_mean), ptr(save_invstd), ptr(dx, x.dtype, cl=True),
+                ptr(dy, x.dtype, cl=True), ptr(dy2, x.dtype, cl=True) if dy2 is not None else None,
+                ptr(y, x.dtype, cl=True) if y is not None else None, ptr(x, x.dtype, cl=True), ptr(weight),
+                ptr(bias) if bias is not None else None, ptr(save_mean), ptr(save_invstd), ptr(dx, x.dtype, cl=True),
                 ptr(dres, x.dtype, cl=True) if has_res else None, ptr(dgamma), ptr(dbeta), Bg, Cc, H, W, groups, int(relu),
                 code, ptr(ws), C.c_size_t(nws), stream()), "mdx_bn_act_nhwc_bwd")
         else:

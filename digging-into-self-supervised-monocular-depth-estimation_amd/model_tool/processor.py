@@ -192,9 +192,9 @@ class compute(object):
             outputs[("R", frame_id, 0)] = axisangle[k * n:(k + 1) * n]
             outputs[("T", frame_id, 0)] = translation[k * n:(k + 1) * n]
         raw = axisangle._base if axisangle._base is not None and axisangle._base is translation._base else None
-        K = inputs[("K", 0)]
+        K = inputs.get(("K", 0))
         if (self.fused_tail and raw is not None and raw.is_cuda and raw.dim() == 4 and raw.shape[-1] == 6 and raw.is_contiguous()
-                and frames == list(opt.frame_ids[1:]) and not K.requires_grad):
+                and frames == list(opt.frame_ids[1:]) and torch.is_tensor(K) and K.is_cuda and not K.requires_grad):
             # every source frame's matrix AND projection from the pose head's output in one launch (one in backward): the
             # reference's row slice + [:, 0] + param2matrix + K @ T per frame is ~10 launches forward and ~30 backward
             T, P = F.pose_projection(raw.float(), K, [k * n for k in range(len(frames))], [0] * len(frames),

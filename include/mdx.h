@@ -355,14 +355,15 @@ int mdx_bn_act_bwd(const void *dy, const void *y, const void *x, const float *ga
  * x, res, y, dy, dx, dres [groups*B][H][W][C]; three launches each way (block partials, a float64 finalize pass, apply),
  * no atomics.  dy2 (may be NULL): a second upstream gradient of y, added on the way in -- a block's output feeds the next
  * block's first convolution AND its identity path, and autograd would otherwise spend one more pass over the map on
- * adding the two. */
+ * adding the two.  bwd with y NULL (relu, no residual: dres NULL; beta given): the ReLU mask is re-derived from x with the forward
+ * pass's own expressions instead of being read -- one map less in each of the two passes (beta is read in that case only). */
 size_t mdx_bn_nhwc_workspace_bytes(int B, int C, int H, int W, int groups, int dtype);
 int mdx_bn_act_nhwc_fwd(const void *x, const void *res, const float *gamma, const float *beta, float *run_mean,
                         float *run_var, void *y, float *save_mean, float *save_invstd, int B, int C, int H, int W,
                         int groups, float eps, float momentum, int relu, int dtype, void *workspace,
                         size_t workspace_bytes, void *stream);
 int mdx_bn_act_nhwc_bwd(const void *dy, const void *dy2, const void *y, const void *x, const float *gamma,
-                        const float *save_mean, const float *save_invstd, void *dx, void *dres, float *dgamma,
+                        const float *beta, const float *save_mean, const float *save_invstd, void *dx, void *dres, float *dgamma,
                         float *dbeta, int B, int C, int H, int W, int groups, int relu, int dtype, void *workspace,
                         size_t workspace_bytes, void *stream);
 /* mdx_decoder_glue_nhwc_*: model_layer/depth_decoder.py:44-47,96-106.  raw [B][h][w][C1], skip [B][u*h][u*w][C2],
