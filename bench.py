@@ -521,6 +521,9 @@ def main():
     ap.add_argument("--no-prologue", action="store_true",
                     help="round-2 form of the photometric path: identity kernel + torch.randn + per-scale target statistics "
                          "instead of the per-step prologue kernel (A/B)")
+    ap.add_argument("--no-fused-tails", action="store_true",
+                    help="round-4 form of the step's small ops (A/B): the scalar tail of the loss as torch ops, the pose head's output "
+                         "sliced per frame into param2matrix + K @ T, the disparity heads as MIOpen convolution + bias + sigmoid")
     ap.add_argument("--no-trainer-loop", action="store_true",
                     help="skip the second measurement (the DataLoader-fed trainer loop, reported as trainer_loop)")
     ap.add_argument("--float-loader", action="store_true",
@@ -598,6 +601,10 @@ def main():
     opt.fused_train = not args.per_scale_kernels
     opt.grad_comm, opt.bucket_mb = args.grad_comm, args.bucket_mb
     opt.prologue = not args.no_prologue
+    opt.fused_tail = not args.no_fused_tails
+    if args.no_fused_tails:
+        from model_layer.depth_decoder import DepthDecoder
+        DepthDecoder.fused_heads = False
     # MIOpen picks the tuned solvers from the shipped find-db in immediate mode already (fp32: same images/s as find
     # mode).  Find mode proper (--miopen-find) returns at once on a db hit but searches for minutes on a miss, so it
     # is never on by default; bf16 networks gain from it (a few more solvers are only reachable through find).

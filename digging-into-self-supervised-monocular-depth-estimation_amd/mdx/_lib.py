@@ -55,6 +55,7 @@ SYMBOLS = {
     "mdx_min_automask_fwd": C.c_int,
     "mdx_loss_total_fwd": C.c_int, "mdx_loss_total_bwd": C.c_int,
     "mdx_pose_projection_fwd": C.c_int, "mdx_pose_projection_bwd": C.c_int,
+    "mdx_disp_head_nhwc_workspace_bytes": C.c_size_t, "mdx_disp_head_nhwc_fwd": C.c_int, "mdx_disp_head_nhwc_bwd": C.c_int,
     "mdx_event_create": C.c_void_p, "mdx_event_destroy": None, "mdx_event_elapsed_us": C.c_int,
     "mdx_photometric_fwd_timed": C.c_int, "mdx_photometric_bwd_timed": C.c_int,
     "mdx_decoder_glue_fwd": C.c_int, "mdx_decoder_glue_bwd": C.c_int, "mdx_decoder_glue_workspace_bytes": C.c_size_t,
@@ -110,14 +111,18 @@ def check(status, what):
 
 
 def ptr(t, dtype=torch.float32, optional=False, cl=False):
-    """Raw device pointer of a contiguous CUDA/HIP tensor (cl: of a 4-D tensor whose memory is channels-last, [B][H][W][C])."""
+    """Raw device pointer of a contiguous CUDA/HIP tensor (cl: of a 4-D tensor whose memory is channels-last, [B][H][W][C];
+    cl="any": dense in either of the two formats -- the caller hands the strides to the kernel)."""
     if t is None:
         if optional:
             return None
         raise MdxError("required tensor is None")
     if not t.is_cuda:
         raise MdxError("mdx kernels run on the GPU only: got a %s tensor (no CPU fallback)" % t.device)
-    if cl:
+    if cl == "any":
+        if t.dtype != dtype or t.dim() != 4 or not (t.is_contiguous() or t.is_contiguous(memory_format=torch.channels_last)):
+            raise MdxError("expected a dense %s 4-D tensor, got %s %s strides %s" % (dtype, t.dtype, tuple(t.shape), t.stride()))
+    elif cl:
         if t.dtype != dtype or t.dim() != 4 or not t.is_contiguous(memory_format=torch.channels_last):
             raise MdxError("expected a channels-last %s map, got %s %s strides %s" % (dtype, t.dtype, tuple(t.shape), t.stride()))
     elif t.dtype != dtype or not t.is_contiguous():

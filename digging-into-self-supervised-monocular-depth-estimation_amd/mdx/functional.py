@@ -781,6 +781,64 @@ def decoder_glue(raw, skip=None, elu=True, upsample=True, out_dtype=None, bias=N
     return _DecoderGlue.apply(raw, skip, bias, bool(elu), bool(upsample), out_dtype)
 
 
+class _DispHead(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        code = _glue_dtype(x, "disp_head")
+        B, Cc, Hp, Wp = x.shape
+        x = _as(x, True)
+        w32 = weight if weight.dtype == torch.float32 else weight.float()
+        if not (w32.is_contiguous() or w32.is_contiguous(memory_format=torch.channels_last)):
+            w32 = w32.contiguous()
+        b32 = None if bias is None else (bias if bias.dtype == torch.float32 else bias.float())
+        disp = torch.empty(B, 1, Hp - 2, Wp - 2, device=x.device, dtype=torch.float32)
+        st = (C.c_int64(w32.stride(1)), C.c_int64(w32.stride(2)), C.c_int64(w32.stride(3)))
+        check(lib().mdx_disp_head_nhwc_fwd(ptr(x, x.dtype, cl=True), ptr(w32, cl="any"), *st, ptr(b32) if b32 is not None else None,
+                                           ptr(disp), B, Cc, Hp - 2, Wp - 2, code, stream()), "mdx_disp_head_nhwc_fwd")
+        ctx.save_for_backward(x, w32, disp)
+        ctx.meta = (weight.dtype, None if bias is None else bias.dtype)
+        return disp
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w32, disp = ctx.saved_tensors
+        wdt, bdt = ctx.meta
+        B, Cc, Hp, Wp = x.shape
+        code = _DTYPE_CODE[x.dtype]
+        g = _f32c(g)
+        gx = torch.empty_like(x)
+        gw = torch.empty_like(w32)                     # the weight's own strides
+        gb = torch.empty(1, device=x.device, dtype=torch.float32) if bdt is not None else None
+        nws = lib().mdx_disp_head_nhwc_workspace_bytes(B, Cc, Hp - 2, Wp - 2, code)
+        ws = torch.empty(nws // 4 + 1, device=x.device, dtype=torch.float32)
+        st = (C.c_int64(w32.stride(1)), C.c_int64(w32.stride(2)), C.c_int64(w32.stride(3)))
+        check(lib().mdx_disp_head_nhwc_bwd(ptr(x, x.dtype, cl=True), ptr(w32, cl="any"), *st, ptr(g), ptr(disp),
+                                           ptr(gx, x.dtype, cl=True), ptr(gw, cl="any"), ptr(gb) if gb is not None else None, B, Cc,
+                                           Hp - 2, Wp - 2, code, ptr(ws), C.c_size_t(nws), stream()), "mdx_disp_head_nhwc_bwd")
+        return gx, gw.to(wdt), (gb.to(bdt) if gb is not None else None)
+
+
+def disp_head_ok(x, weight):
+    """Can disp_head take this padded map and this head's weight?  (channels-last GPU map, one output channel, 3x3, a channel count
+    that is a power-of-two number of 16-byte vectors up to 64.)"""
+    if not (x.is_cuda and x.dim() == 4 and x.dtype in _DTYPE_CODE and is_channels_last(x)):
+        return False
+    n = 16 // x.element_size()
+    lp = x.shape[1] // n
+    return (tuple(weight.shape) == (1, x.shape[1], 3, 3) and x.shape[1] % n == 0 and 1 <= lp <= 64 and lp & (lp - 1) == 0
+            and x.shape[2] > 2 and x.shape[3] > 2)
+
+
+def disp_head(x, weight, bias=None):
+    """sigmoid(conv2d(x, weight, bias)) for a disparity head (depth_decoder.py:73-74,108-110): x [B,C,h+2,w+2] the reflection-padded,
+    channels-last input, weight [1,C,3,3], bias [1] -> disp [B,1,h,w] float32 (csrc/disp_head_nhwc.hip: one launch forward, one +
+    a finishing pass backward; float32 accumulation whatever x's dtype)."""
+    if not disp_head_ok(x, weight):
+        raise _lib.MdxError("disp_head: needs a channels-last GPU map [B,C,h+2,w+2] with C a power-of-two number of 16-byte vectors "
+                            "and a [1,C,3,3] weight; got x %s %s, weight %s" % (tuple(x.shape), x.dtype, tuple(weight.shape)))
+    return _DispHead.apply(x, weight, bias)
+
+
 class _MaxPool3s2(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, fork):

@@ -38,6 +38,8 @@ class ConvBlock(nn.Module):
 
 
 class DepthDecoder(nn.Module):
+    fused_heads = True          # False: the heads as MIOpen convolution + bias + sigmoid (A/B, parity tests)
+
     def __init__(self, num_ch_enc, scales=range(4), num_output_channels=1, use_skips=True):
         super().__init__()
         self.num_ch_enc = num_ch_enc
@@ -103,6 +105,12 @@ class DepthDecoder(nn.Module):
                 # head + sigmoid stay float32 under bf16 autocast: the photometric kernels consume float32
                 head_in = padded if (padded is not None and padded.dtype == torch.float32) else \
                     F.decoder_glue(raw, None, elu=True, upsample=False, out_dtype=torch.float32, bias=bias)
-                with torch.autocast(device_type="cuda", enabled=False):
-                    self.outputs[("disp", i)] = self.sigmoid(self.decoder[self._head[i]].conv(head_in))
+                head = self.decoder[self._head[i]].conv
+                if self.fused_heads and F.disp_head_ok(head_in, head.weight):
+                    # one output channel is no matrix-core problem: convolution + bias + sigmoid in one hand-written launch,
+                    # data / weight / bias gradient in one more (csrc/disp_head_nhwc.hip)
+                    self.outputs[("disp", i)] = F.disp_head(head_in, head.weight, head.bias)
+                else:
+                    with torch.autocast(device_type="cuda", enabled=False):
+                        self.outputs[("disp", i)] = self.sigmoid(head(head_in))
         return self.outputs

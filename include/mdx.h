@@ -366,6 +366,19 @@ int mdx_bn_act_nhwc_bwd(const void *dy, const void *dy2, const void *y, const vo
                         const float *beta, const float *save_mean, const float *save_invstd, void *dx, void *dres, float *dgamma,
                         float *dbeta, int B, int C, int H, int W, int groups, int relu, int dtype, void *workspace,
                         size_t workspace_bytes, void *stream);
+/* The decoder's disparity heads   model_layer/depth_decoder.py:73-74,108-110: sigmoid(Conv3x3(C -> 1)(x)) on a channels-last map.
+ * x [B][h+2][w+2][C] = the reflection-padded input (mdx_decoder_glue_nhwc_fwd's output), dtype 0 float32 / 1 bfloat16, C a
+ * power-of-two multiple of the 16-byte vector (4 / 8 elements) up to 64 vectors; weight: float32, element (c, ky, kx) at
+ * weight[c * w_stride_c + ky * w_stride_ky + kx * w_stride_kx] (planar [1,C,3,3]: 9, 3, 1; channels-last: 1, 3C, C);
+ * bias [1] (may be NULL) -> disp [B][h][w] float32.  One launch.
+ * bwd: gdisp, disp [B][h][w] -> gx (x's dtype and shape), gweight (the weight's strides), gbias [1] (may be NULL): one launch
+ * that reads x once and writes gx once + a finishing pass over the block partials (fixed order, no atomics). */
+size_t mdx_disp_head_nhwc_workspace_bytes(int B, int C, int h, int w, int dtype);
+int mdx_disp_head_nhwc_fwd(const void *x, const float *weight, int64_t w_stride_c, int64_t w_stride_ky, int64_t w_stride_kx,
+                           const float *bias, float *disp, int B, int C, int h, int w, int dtype, void *stream);
+int mdx_disp_head_nhwc_bwd(const void *x, const float *weight, int64_t w_stride_c, int64_t w_stride_ky, int64_t w_stride_kx,
+                           const float *gdisp, const float *disp, void *gx, float *gweight, float *gbias, int B, int C, int h,
+                           int w, int dtype, void *workspace, size_t workspace_bytes, void *stream);
 /* mdx_decoder_glue_nhwc_*: model_layer/depth_decoder.py:44-47,96-106.  raw [B][h][w][C1], skip [B][u*h][u*w][C2],
  * out / gout [B][u*h+2][u*w+2][C1+C2]; dtype pairs as mdx_decoder_glue_fwd. */
 int mdx_decoder_glue_nhwc_fwd(const void *raw, const void *skip, const float *bias, void *out, int B, int C1, int C2,

@@ -396,3 +396,81 @@ def test_param2matrix_kernel_matches_torch_ops(F, invert):
     ok = aa0.abs().sum((1, 2)) > 0                     # at the exact origin |a| has no gradient: both give a finite value
     torch.testing.assert_close(a1.grad.double().cpu()[ok], a2.grad[ok], rtol=2e-4, atol=2e-4)
     assert torch.isfinite(a1.grad).all()
+
+
+HEAD_CASES = [(2, 16, 6, 10), (1, 16, 33, 70), (3, 32, 5, 7), (2, 64, 9, 4), (1, 128, 13, 21), (2, 256, 3, 5), (12, 16, 48, 160),
+              (2, 16, 1, 1), (1, 32, 2, 65)]
+
+
+@pytest.mark.parametrize("wcl", [False, True])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cfg", HEAD_CASES)
+def test_disp_head_matches_conv_bias_sigmoid(F, cfg, dtype, wcl):
+    """disp_head == sigmoid(conv2d(x, w, b)) with one output channel (depth_decoder.py:73-74,108-110), forward and the three
+    gradients, weight in either memory format.  float32 maps: 2e-6 / 1e-5 relative to the largest entry; bfloat16 maps against
+    the float32 convolution of the SAME (bf16-rounded) input: the kernel accumulates in float32."""
+    B, Cc, h, w = cfg
+    if dtype == torch.bfloat16 and Cc % 8:
+        pytest.skip("bfloat16 vectors hold 8 channels")
+    g = torch.Generator().manual_seed(3)
+    x = _leaf(torch.randn(B, Cc, h + 2, w + 2, generator=g), dtype, True)
+    wt = (0.2 * torch.randn(1, Cc, 3, 3, generator=g)).cuda()
+    if wcl:
+        wt = wt.contiguous(memory_format=torch.channels_last)
+    wt.requires_grad_(True)
+    b = torch.randn(1, generator=g).cuda().requires_grad_(True)
+    gy = torch.randn(B, 1, h, w, generator=g).cuda()
+    assert F.disp_head_ok(x, wt)
+    y = F.disp_head(x, wt, b)
+    assert y.dtype == torch.float32 and y.shape == (B, 1, h, w)
+    gx, gw, gb = torch.autograd.grad(y, (x, wt, b), gy)
+    assert gx.dtype == dtype and _layout_is(gx, True) and gw.shape == wt.shape and gw.stride() == wt.stride()
+    xr = x.detach().double().requires_grad_(True)
+    wr, br = wt.detach().double().requires_grad_(True), b.detach().double().requires_grad_(True)
+    yr = torch.sigmoid(torch.nn.functional.conv2d(xr, wr, br))
+    gxr, gwr, gbr = torch.autograd.grad(yr, (xr, wr, br), gy.double())
+
+    def close(a, ref, tol, what):
+        d = float((a.double() - ref).abs().max())
+        assert d <= tol * max(1e-30, float(ref.abs().max())), (what, d, float(ref.abs().max()))
+    close(y, yr, 2e-6, "disp")
+    close(gx, gxr, 2e-6 if dtype == torch.float32 else 8e-3, "gx")          # gx is stored in x's dtype
+    close(gw, gwr, 1e-5, "gw")
+    close(gb, gbr, 1e-5, "gb")
+
+
+def test_disp_head_refuses_what_it_cannot_take(F):
+    x = torch.randn(1, 24, 6, 6).cuda().contiguous(memory_format=torch.channels_last)      # 6 vectors: not a power of two
+    w = torch.randn(1, 24, 3, 3).cuda()
+    assert not F.disp_head_ok(x, w)
+    with pytest.raises(Exception):
+        F.disp_head(x, w)
+    assert not F.disp_head_ok(torch.randn(1, 16, 6, 6).cuda(), torch.randn(1, 16, 3, 3).cuda())          # planar map
+    assert not F.disp_head_ok(x[:, :16].contiguous(memory_format=torch.channels_last), torch.randn(2, 16, 3, 3).cuda())
+
+
+def test_decoder_with_fused_heads_equals_miopen_heads():
+    """DepthDecoder with the hand-written heads against the same decoder with MIOpen convolution + bias + sigmoid heads:
+    disparities and every parameter gradient."""
+    from model_layer.depth_decoder import DepthDecoder
+    from mdx.layout import apply_plan
+    torch.manual_seed(0)
+    enc = [64, 64, 128, 256, 512]
+    dec = DepthDecoder(enc).cuda()
+    apply_plan({"decoder": dec}, "all")
+    feats = [torch.randn(2, c, 32 >> i, 64 >> i).cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+             for i, c in enumerate(enc)]
+    res = []
+    for fused in (True, False):
+        dec.fused_heads = fused
+        dec.zero_grad(set_to_none=True)
+        out = dec(feats)
+        loss = sum((out[("disp", s)] * (s + 1.0)).square().mean() for s in range(4))
+        grads = torch.autograd.grad(loss, list(dec.parameters()) + feats)
+        res.append(([out[("disp", s)].detach() for s in range(4)], grads))
+    dec.fused_heads = True
+    (da, ga), (db, gb) = res
+    for s in range(4):
+        assert float((da[s] - db[s]).abs().max()) <= 2e-6, s
+    for a, b in zip(ga, gb):
+        assert float((a - b).abs().max()) <= 2e-5 * max(1e-30, float(b.abs().max())) + 1e-9

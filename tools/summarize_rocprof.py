@@ -21,8 +21,8 @@ def main():
              "# total kernel time %.3f ms over %d distinct kernels" % (tot / 1e6, len(rows)),
              "%-92s %7s %11s %10s %10s %10s %6s" % ("kernel", "calls", "total_ms", "avg_us", "min_us", "max_us", "%")]
     mdx = [r for r in rows if "mdx::" in r["Name"]]
-    others = [r for r in rows if "mdx::" not in r["Name"]][:15]
-    for group, title in ((mdx, "## hand-written kernels (libmdx_hip.so)"), (others, "## top 15 other kernels (MIOpen / ATen)")):
+    others = [r for r in rows if "mdx::" not in r["Name"]][:60]
+    for group, title in ((mdx, "## hand-written kernels (libmdx_hip.so)"), (others, "## top 60 other kernels (MIOpen / ATen)")):
         lines.append(title)
         for r in group:
             lines.append("%-92s %7s %11.3f %10.2f %10.2f %10.2f %6.2f" % (
