@@ -102,10 +102,15 @@ class DepthDecoder(nn.Module):
             raw, bias = conv(self.decoder[second], F.decoder_glue(raw, skip, elu=True, upsample=True, bias=bias))
             padded = F.decoder_glue(raw, None, elu=True, upsample=False, bias=bias) if i > 0 else None
             if i in self._head:
-                # head + sigmoid stay float32 under bf16 autocast: the photometric kernels consume float32
-                head_in = padded if (padded is not None and padded.dtype == torch.float32) else \
-                    F.decoder_glue(raw, None, elu=True, upsample=False, out_dtype=torch.float32, bias=bias)
                 head = self.decoder[self._head[i]].conv
+                # The hand-written head accumulates in float32 and writes float32 whatever its input's dtype: under bf16 autocast it
+                # reads the bf16 padded map the next stage reads anyway (scale 0: a bf16 one of its own).  The MIOpen form keeps head
+                # + sigmoid in float32 on a float32 copy of the map: the photometric kernels consume float32.
+                if self.fused_heads and raw.dtype != torch.float32 and cl:
+                    head_in = padded if padded is not None else F.decoder_glue(raw, None, elu=True, upsample=False, bias=bias)
+                else:
+                    head_in = padded if (padded is not None and padded.dtype == torch.float32) else \
+                        F.decoder_glue(raw, None, elu=True, upsample=False, out_dtype=torch.float32, bias=bias)
                 if self.fused_heads and F.disp_head_ok(head_in, head.weight):
                     # one output channel is no matrix-core problem: convolution + bias + sigmoid in one hand-written launch,
                     # data / weight / bias gradient in one more (csrc/disp_head_nhwc.hip)
