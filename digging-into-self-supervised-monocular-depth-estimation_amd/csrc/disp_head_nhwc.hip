@@ -50,9 +50,16 @@ __global__ __launch_bounds__(DH_NB) void disp_head_fwd_kernel(const T *__restric
     const T *px = x + ((size_t)b * Hp * Wp + jc) * C + (size_t)l * N;
     const size_t rs = (size_t)Wp * C;
     float r1 = 0.f, r2 = 0.f;
+    // the next row's loads are issued before this row's arithmetic: a thread walks its rows one after the other, and without the
+    // prefetch every row costs a full memory latency
+    Vec<T, N> n0 = load_vec<T, N>(px + (size_t)i0 * rs), n1 = load_vec<T, N>(px + (size_t)i0 * rs + C),
+              n2 = load_vec<T, N>(px + (size_t)i0 * rs + 2 * C);
     for (int p = i0; p < i1 + 2; ++p) {          // input row p feeds output rows p, p-1, p-2 through kernel rows 0, 1, 2
-        const T *row = px + (size_t)p * rs;
-        const Vec<T, N> v0 = load_vec<T, N>(row), v1 = load_vec<T, N>(row + C), v2 = load_vec<T, N>(row + 2 * C);
+        const Vec<T, N> v0 = n0, v1 = n1, v2 = n2;
+        if (p + 1 < i1 + 2) {
+            const T *row = px + (size_t)(p + 1) * rs;
+            n0 = load_vec<T, N>(row); n1 = load_vec<T, N>(row + C); n2 = load_vec<T, N>(row + 2 * C);
+        }
         float s0 = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int n = 0; n < N; ++n) {
@@ -75,8 +82,8 @@ __global__ __launch_bounds__(DH_NB) void disp_head_fwd_kernel(const T *__restric
 }
 
 // grid (ceil(Wp / CPB), ceil(Hp / R), B); part [blocks][9 * C + 1]: the block's weight-gradient partials [ky][kx][c] and its bias one
-template <typename T>
-__global__ __launch_bounds__(DH_NB) void disp_head_bwd_kernel(const T *__restrict__ x, const float *__restrict__ wt, long wsc, long wsy,
+template <typename T, int WAVES>      // WAVES: the occupancy the register allocator is held to (float32: 4 -> 124 registers, no spill)
+__global__ __launch_bounds__(DH_NB) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void disp_head_bwd_kernel(const T *__restrict__ x, const float *__restrict__ wt, long wsc, long wsy,
                                                               long wsx, const float *__restrict__ g, const float *__restrict__ y, int Hp,
                                                               int Wp, int C, int LP, int R, T *__restrict__ gx, float *__restrict__ part)
 {
@@ -90,26 +97,44 @@ __global__ __launch_bounds__(DH_NB) void disp_head_bwd_kernel(const T *__restric
     const int p0 = blockIdx.y * R, p1 = min(p0 + R, Hp), b = blockIdx.z;
     float wr[9][N];
     load_weights<T, N>(wt, wsc, wsy, wsx, l * N, wr);
-    auto gpre = [&](int i, int jj) -> float {    // d loss / d (convolution output): sigmoid_backward's  g * (1 - y) * y
-        if (i < 0 || i >= h || jj < 0 || jj >= w) return 0.f;
-        const size_t o = ((size_t)b * h + i) * w + jj;
-        const float yy = y[o];
-        return g[o] * (1.0f - yy) * yy;
+    // d loss / d (convolution output) = sigmoid_backward's  g * (1 - y) * y; loaded raw (0 outside the map) so that the next row's
+    // loads can be issued before this row's arithmetic
+    auto raw = [&](int i, int jj, float &gv, float &yv) {
+        gv = 0.f; yv = 0.f;
+        if (i >= 0 && i < h && jj >= 0 && jj < w) {
+            const size_t o = ((size_t)b * h + i) * w + jj;
+            gv = g[o]; yv = y[o];
+        }
     };
+    auto gpre = [&](float gv, float yv) -> float { return gv * (1.0f - yv) * yv; };
     float G[3][3];                               // G[ky][kx] = gpre(p - ky, q - kx): the outputs input element (p, q) feeds
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) { G[1][kx] = gpre(p0 - 1, q - kx); G[2][kx] = gpre(p0 - 2, q - kx); }
+    for (int kx = 0; kx < 3; ++kx) {
+        float gv, yv;
+        raw(p0 - 1, q - kx, gv, yv); G[1][kx] = gpre(gv, yv);
+        raw(p0 - 2, q - kx, gv, yv); G[2][kx] = gpre(gv, yv);
+    }
     float gw[9][N], gb = 0.f;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int n = 0; n < N; ++n) gw[t][n] = 0.f;
     const size_t col = (size_t)qc * C + (size_t)l * N;
-    for (int p = p0; p < p1; ++p) {
+    const size_t rs = (size_t)Wp * C;
+    size_t off = ((size_t)b * Hp + p0) * rs + col;
+    Vec<T, N> xn = load_vec<T, N>(x + off);
+    float gn[3], yn[3];
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) G[0][kx] = gpre(p, q - kx);
-        const size_t off = ((size_t)b * Hp + p) * Wp * C + col;
-        const Vec<T, N> xv = load_vec<T, N>(x + off);
+    for (int kx = 0; kx < 3; ++kx) raw(p0, q - kx, gn[kx], yn[kx]);
+    for (int p = p0; p < p1; ++p, off += rs) {
+        const Vec<T, N> xv = xn;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) G[0][kx] = gpre(gn[kx], yn[kx]);
+        if (p + 1 < p1) {
+            xn = load_vec<T, N>(x + off + rs);
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) raw(p + 1, q - kx, gn[kx], yn[kx]);
+        }
         Vec<T, N> o;
 #pragma unroll
         for (int n = 0; n < N; ++n) {
@@ -263,10 +288,10 @@ MDX_EXPORT int mdx_disp_head_nhwc_bwd(const void *x, const float *weight, int64_
     const size_t shmem = ((size_t)(DH_NB / 64) * 9 * C + DH_NB / 64) * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MDX_F32)
-        hipLaunchKernelGGL((disp_head_bwd_kernel<float>), g.grid, dim3(DH_NB), shmem, st, (const float *)x, weight, (long)w_stride_c,
+        hipLaunchKernelGGL((disp_head_bwd_kernel<float, 4>), g.grid, dim3(DH_NB), shmem, st, (const float *)x, weight, (long)w_stride_c,
                            (long)w_stride_ky, (long)w_stride_kx, gdisp, disp, h + 2, w + 2, C, g.LP, g.R, (float *)gx, part);
     else
-        hipLaunchKernelGGL((disp_head_bwd_kernel<bf16>), g.grid, dim3(DH_NB), shmem, st, (const bf16 *)x, weight, (long)w_stride_c,
+        hipLaunchKernelGGL((disp_head_bwd_kernel<bf16, 2>), g.grid, dim3(DH_NB), shmem, st, (const bf16 *)x, weight, (long)w_stride_c,
                            (long)w_stride_ky, (long)w_stride_kx, gdisp, disp, h + 2, w + 2, C, g.LP, g.R, (bf16 *)gx, part);
     const int nblk = (int)(g.grid.x * g.grid.y * g.grid.z), cols = 9 * C + 1;
     hipLaunchKernelGGL(disp_head_finish_kernel, dim3((cols + DF_C - 1) / DF_C), dim3(DF_C * DF_S), 0, st, part, nblk, C,

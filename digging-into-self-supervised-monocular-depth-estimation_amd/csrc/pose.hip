@@ -218,10 +218,16 @@ __global__ __launch_bounds__(64) void pose_projection_bwd_kernel(const float *__
     const int mrow = e / F, f = e - mrow * F;
     float g[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const float *p = raw + (size_t)e * 6;
+    // NOT unrolled: the body is the whole dual-number evaluation; this kernel runs once per step with a cold instruction cache, and
+    // four copies of it cost more than the loop (45 us -> see profiles/)
+#pragma unroll 1
+    for (int s = 0; s < S; ++s) {
+        int row0 = sel.row0[0], frame = sel.frame[0], inv = sel.invert[0];
 #pragma unroll
-    for (int s = 0; s < MDX_MAX_SRC; ++s) {
-        if (s >= S || f != sel.frame[s] || mrow < sel.row0[s] || mrow >= sel.row0[s] + B) continue;
-        const int b = mrow - sel.row0[s];
+        for (int k = 1; k < MDX_MAX_SRC; ++k)
+            if (s == k) { row0 = sel.row0[k]; frame = sel.frame[k]; inv = sel.invert[k]; }
+        if (f != frame || mrow < row0 || mrow >= row0 + B) continue;
+        const int b = mrow - row0;
         const size_t n = (size_t)s * B + b;
         Dual<6> a[3], t[3], m[12];
 #pragma unroll
@@ -231,7 +237,7 @@ __global__ __launch_bounds__(64) void pose_projection_bwd_kernel(const float *__
             t[i] = mk<6>(p[3 + i]);
             t[i].d[3 + i] = 1.0f;
         }
-        pose_matrix<6>(a, t, sel.invert[s] != 0, m);
+        pose_matrix<6>(a, t, inv != 0, m);
         const float *Kb = K + 16 * (size_t)b;
 #pragma unroll
         for (int k = 0; k < 3; ++k)
