@@ -523,7 +523,8 @@ def main():
                          "instead of the per-step prologue kernel (A/B)")
     ap.add_argument("--no-fused-tails", action="store_true",
                     help="round-4 form of the step's small ops (A/B): the scalar tail of the loss as torch ops, the pose head's output "
-                         "sliced per frame into param2matrix + K @ T, the disparity heads as MIOpen convolution + bias + sigmoid")
+                         "sliced per frame into param2matrix + K @ T, the disparity heads as MIOpen convolution + bias + sigmoid, the pose "
+                         "decoder's bias / ReLU / mean as ATen ops")
     ap.add_argument("--no-trainer-loop", action="store_true",
                     help="skip the second measurement (the DataLoader-fed trainer loop, reported as trainer_loop)")
     ap.add_argument("--float-loader", action="store_true",
@@ -604,7 +605,9 @@ def main():
     opt.fused_tail = not args.no_fused_tails
     if args.no_fused_tails:
         from model_layer.depth_decoder import DepthDecoder
+        from model_layer.pose_decoder import PoseDecoder
         DepthDecoder.fused_heads = False
+        PoseDecoder.fused_tail = False
     # MIOpen picks the tuned solvers from the shipped find-db in immediate mode already (fp32: same images/s as find
     # mode).  Find mode proper (--miopen-find) returns at once on a db hit but searches for minutes on a miss, so it
     # is never on by default; bf16 networks gain from it (a few more solvers are only reachable through find).

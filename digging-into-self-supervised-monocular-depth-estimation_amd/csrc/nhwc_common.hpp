@@ -59,5 +59,66 @@ static inline Tile make_tile(int C, int N)
     return t;
 }
 
+// ---- a map as a matrix [M rows][C]: blocks own row ranges, a thread one channel vector and every PL-th row -------------------
+struct Rows {
+    Tile t;
+    int RB;        // rows a block owns (multiple of t.PL)
+    int nblk;      // blocks along the rows
+};
+static inline Rows make_rows(long long M, int C, int N, int max_blocks, int min_iters)
+{
+    Rows g;
+    g.t = make_tile(C, N);
+    const long long rows_min = (long long)g.t.PL * min_iters;
+    long long nb = (M + rows_min - 1) / rows_min;
+    if (nb > max_blocks) nb = max_blocks;
+    if (nb < 1) nb = 1;
+    long long RB = (M + nb - 1) / nb;
+    RB = (RB + g.t.PL - 1) / g.t.PL * g.t.PL;
+    g.RB = (int)RB;
+    g.nblk = (int)((M + RB - 1) / RB);
+    return g;
+}
+struct Pos { int cv, pl, r0, r1, g; bool active; };
+template <int N> __device__ __forceinline__ Pos position(int M, int C, int CVB, int PL, int RB)
+{
+    Pos p;
+    const int t = threadIdx.x;
+    const int cvl = t % CVB;
+    p.pl = t / CVB;
+    p.cv = blockIdx.y * CVB + cvl;
+    p.g = blockIdx.z;
+    p.r0 = blockIdx.x * RB;
+    p.r1 = min(M, p.r0 + RB);
+    p.active = p.pl < PL && p.cv * N < C;
+    return p;
+}
+
+// sum the block's per-thread vectors over the pixel lanes (fixed order) and write one partial per channel
+template <int N>
+__device__ __forceinline__ void block_partials(const float (&a)[N], const float (&q)[N], float *lds, int CVB, int PL, int C,
+                                               float *__restrict__ part_blk /* [2][C] of this (group, block) */)
+{
+    float *la = lds, *lq = lds + NB * N;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        la[threadIdx.x * N + j] = a[j];
+        lq[threadIdx.x * N + j] = q[j];
+    }
+    __syncthreads();
+    const int width = CVB * N;                               // channels this block covers
+    for (int e = threadIdx.x; e < width; e += NB) {
+        const int c = blockIdx.y * width + e;
+        if (c >= C) break;
+        float sa = 0.f, sq = 0.f;
+        for (int l = 0; l < PL; ++l) {
+            sa += la[l * width + e];
+            sq += lq[l * width + e];
+        }
+        part_blk[c] = sa;
+        part_blk[C + c] = sq;
+    }
+}
+
 }  // namespace nhwc
 }  // namespace mdx

@@ -405,8 +405,14 @@ class _TrainLoss(torch.autograd.Function):
         Pl, disps = tensors[:nP], tensors[nP:]
         nsc = len(disps)
         grads = cfg.get("grads", True)
-        # the smoothness launches go BETWEEN the prologue and the training kernel (processor.compute_loss explains why)
-        smooth, gs = _smooth_multi_launch(True, colors, disps, grads)
+        # the smoothness launches go BETWEEN the prologue and the training kernel (processor.compute_loss explains why) -- or
+        # were issued ahead of this node (smooth_launch)
+        if cfg.get("smooth") is not None:
+            smooth, gs = cfg["smooth"]
+            if grads and gs is None:
+                raise _lib.MdxError("train_loss: the smoothness passes were launched without their gradients")
+        else:
+            smooth, gs = _smooth_multi_launch(True, colors, disps, grads)
         r = _train_launch(cfg, target, invK, ident, noises, sources, Pl, disps)
         total = torch.empty((), device=target.device, dtype=torch.float32)
         scales = (C.c_int32 * nsc)(*[int(v) for v in cfg["scales"]])
@@ -444,8 +450,15 @@ class _TrainLoss(torch.autograd.Function):
         return (None,) * 8 + gPs + tuple(o.to(dt) for o, dt in zip(out, ddt))
 
 
+def smooth_launch(disps, colors, need_grad=True):
+    """The smoothness passes of a step issued on their own (no autograd node): (loss [nscales], unit-upstream gradients or None),
+    to be handed to train_loss(smooth=...) -- for a caller that wants them on the stream before the training kernel's other
+    inputs are ready."""
+    return _smooth_multi_launch(True, list(colors), [d.detach() for d in disps], bool(need_grad))
+
+
 def train_loss(disps, P, target, sources, invK, colors, scales, disp_smoothness, ident=None, noises=None, automask=True,
-               min_depth=0.1, max_depth=100.0, need_depth=False, pre=None):
+               min_depth=0.1, max_depth=100.0, need_depth=False, pre=None, smooth=None):
     """outputs["loss"] of a training step (processor.py:163-217) from the disparities and the projections: smoothness
     (smooth_loss_multi), photometric term (photometric_train) and the scalar tail, one autograd node.  colors: the target at
     every scale; scales: opt.scales.  Returns dict: 'loss' (scalar, differentiable), 'sums', 'smooth' [nscales], 'idx', 'depth'.
@@ -459,7 +472,7 @@ def train_loss(disps, P, target, sources, invK, colors, scales, disp_smoothness,
     grads = torch.is_grad_enabled() and any(t.requires_grad for t in list(disps) + Pl)
     cfg = dict(automask=bool(automask), min_depth=float(min_depth), max_depth=float(max_depth), need_depth=bool(need_depth),
                need_to_opt=False, rows_per_chunk=0, grads=grads, pre=pre, scales=[int(v) for v in scales],
-               disp_smoothness=float(disp_smoothness))
+               disp_smoothness=float(disp_smoothness), smooth=smooth)
     n = len(disps)
     out = _TrainLoss.apply(target, invK, ident, cfg, list(noises) if noises is not None else None, list(sources),
                            list(colors), len(Pl), *Pl, *disps)
@@ -779,6 +792,82 @@ def decoder_glue(raw, skip=None, elu=True, upsample=True, out_dtype=None, bias=N
     if skip is not None and skip.dtype != raw.dtype:
         skip = skip.to(raw.dtype)
     return _DecoderGlue.apply(raw, skip, bias, bool(elu), bool(upsample), out_dtype)
+
+
+class _BiasAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, bias, relu):
+        code = _glue_dtype(x, "bias_act")
+        B, Cc, H, W = x.shape
+        x = _as(x, True)
+        b32 = bias if bias.dtype == torch.float32 else bias.float()
+        y = torch.empty_like(x)
+        check(lib().mdx_bias_act_nhwc_fwd(ptr(x, x.dtype, cl=True), ptr(b32), ptr(y, x.dtype, cl=True), B, Cc, H, W, int(relu), code,
+                                          stream()), "mdx_bias_act_nhwc_fwd")
+        ctx.save_for_backward(y)
+        ctx.meta = (bool(relu), bias.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        relu, bdt = ctx.meta
+        B, Cc, H, W = y.shape
+        code = _DTYPE_CODE[y.dtype]
+        dy = _as(dy.to(y.dtype), True)
+        dx = torch.empty_like(y)
+        db = torch.empty(Cc, device=y.device, dtype=torch.float32)
+        nws = lib().mdx_bias_act_nhwc_workspace_bytes(B, Cc, H, W, code)
+        ws = torch.empty(nws // 4 + 1, device=y.device, dtype=torch.float32)
+        check(lib().mdx_bias_act_nhwc_bwd(ptr(dy, y.dtype, cl=True), ptr(y, y.dtype, cl=True), ptr(dx, y.dtype, cl=True), ptr(db), B, Cc,
+                                          H, W, int(relu), code, ptr(ws), C.c_size_t(nws), stream()), "mdx_bias_act_nhwc_bwd")
+        return dx, db.to(bdt), None
+
+
+def bias_act_ok(x):
+    """Can bias_act take this map?  (channels-last GPU map, float32 / bfloat16, whole 16-byte channel vectors.)"""
+    return (x.is_cuda and x.dim() == 4 and x.dtype in _DTYPE_CODE and is_channels_last(x) and _nhwc_ok(x.dtype, x.shape[1]))
+
+
+def bias_act(x, bias, relu=True):
+    """act(x + bias[None, :, None, None]) on a channels-last map (csrc/pose_head_nhwc.hip): what follows each of the pose decoder's
+    convolutions (pose_decoder.py:24-50) when the convolution runs without its bias -- one launch; backward one launch for dx and
+    the bias gradient's block partials + a finishing pass."""
+    if not bias_act_ok(x):
+        raise _lib.MdxError("bias_act: needs a channels-last GPU map with whole 16-byte channel vectors, got %s %s" % (tuple(x.shape), x.dtype))
+    return _BiasAct.apply(x, bias, bool(relu))
+
+
+class _MeanBias(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, bias, scale):
+        code = _glue_dtype(x, "mean_bias")
+        B, Cc, H, W = x.shape
+        x = _as(x, True)
+        b32 = None if bias is None else (bias if bias.dtype == torch.float32 else bias.float())
+        out = torch.empty(B, Cc, device=x.device, dtype=torch.float32)
+        check(lib().mdx_mean_bias_nhwc_fwd(ptr(x, x.dtype, cl=True), ptr(b32) if b32 is not None else None, ptr(out), B, Cc, H, W,
+                                           C.c_float(scale), code, stream()), "mdx_mean_bias_nhwc_fwd")
+        ctx.meta = (tuple(x.shape), x.dtype, float(scale), None if bias is None else bias.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (B, Cc, H, W), dt, scale, bdt = ctx.meta
+        g = _f32c(g)
+        dx = torch.empty((B, Cc, H, W), device=g.device, dtype=dt, memory_format=_CL)
+        db = torch.empty(Cc, device=g.device, dtype=torch.float32) if bdt is not None else None
+        check(lib().mdx_mean_bias_nhwc_bwd(ptr(g), ptr(dx, dt, cl=True), ptr(db) if db is not None else None, B, Cc, H, W,
+                                           C.c_float(scale), _DTYPE_CODE[dt], stream()), "mdx_mean_bias_nhwc_bwd")
+        return dx, (db.to(bdt) if db is not None else None), None
+
+
+def mean_bias(x, bias=None, scale=1.0):
+    """scale * (x.mean((2, 3)) + bias) -> [B, C] float32 for a channels-last GPU map: the pose head's spatial mean and 0.01
+    (pose_decoder.py:51-53) behind a convolution that ran without its bias.  One launch each way."""
+    if not (x.is_cuda and x.dim() == 4 and x.dtype in _DTYPE_CODE and is_channels_last(x)):
+        raise _lib.MdxError("mean_bias: needs a channels-last GPU map, got %s %s" % (tuple(x.shape), x.dtype))
+    return _MeanBias.apply(x, bias, float(scale))
 
 
 class _DispHead(torch.autograd.Function):

@@ -47,6 +47,21 @@ def device_key(key):
     return step_reads(key) and key not in HOST_KEYS
 
 
+def _pose_head_output(axisangle, translation):
+    """The [M, F, 1, 6] tensor the pose head returned as (x[..., :3], x[..., 3:]) (pose_decoder.py:53-56), or None when the two
+    are not those views of one dense tensor."""
+    base = axisangle._base
+    if base is None or base is not translation._base or not base.is_contiguous() or axisangle.dim() != 4:
+        return None
+    M, Fr = axisangle.shape[0], axisangle.shape[1]
+    want = (Fr * 6, 6, 6, 1)
+    if (base.numel() != M * Fr * 6 or tuple(axisangle.shape) != (M, Fr, 1, 3) or tuple(translation.shape) != (M, Fr, 1, 3)
+            or axisangle.stride() != want or translation.stride() != want
+            or axisangle.storage_offset() != base.storage_offset() or translation.storage_offset() != base.storage_offset() + 3):
+        return None
+    return base.view(M, Fr, 1, 6)
+
+
 class compute(object):
     def __init__(self, opt, device):
         self.opt = opt
@@ -191,9 +206,9 @@ class compute(object):
         for k, frame_id in enumerate(frames):
             outputs[("R", frame_id, 0)] = axisangle[k * n:(k + 1) * n]
             outputs[("T", frame_id, 0)] = translation[k * n:(k + 1) * n]
-        raw = axisangle._base if axisangle._base is not None and axisangle._base is translation._base else None
+        raw = _pose_head_output(axisangle, translation)
         K = inputs.get(("K", 0))
-        if (self.fused_tail and raw is not None and raw.is_cuda and raw.dim() == 4 and raw.shape[-1] == 6 and raw.is_contiguous()
+        if (self.fused_tail and raw is not None and raw.is_cuda
                 and frames == list(opt.frame_ids[1:]) and torch.is_tensor(K) and K.is_cuda and not K.requires_grad):
             # every source frame's matrix AND projection from the pose head's output in one launch (one in backward): the
             # reference's row slice + [:, 0] + param2matrix + K @ T per frame is ~10 launches forward and ~30 backward
@@ -287,6 +302,28 @@ class compute(object):
             return torch.randn(shape).to(self.device)
         return torch.randn(shape, device=self.device)
 
+    def loss_prologue(self, inputs, outputs):
+        """The launches of compute_loss that need the batch and the disparities only -- the prologue kernel (identity losses, noise,
+        the target's window statistics) and the smoothness passes -- issued NOW and kept for compute_loss.  A caller that runs the
+        pose network beside the depth network calls this on the depth network's stream before it joins the pose stream: 66 us of
+        kernels leave the stretch of the step where nothing else can run.  Does nothing unless the step takes the default path
+        (one-launch training kernel, fused tail, in-kernel noise)."""
+        opt = self.opt
+        target = inputs[("color", 0, 0)]
+        if not (self.fused and self.fused_train and self.fused_tail and self.prologue and len(opt.scales) <= 4 and target.is_cuda
+                and torch.is_grad_enabled() and all(("disp", s) in outputs for s in opt.scales)):
+            return
+        automask = bool(opt.use_automasking)
+        if automask and (self.noise_mode == "cpu" or any(("noise", s) in inputs for s in opt.scales)):
+            return
+        sources = [inputs[("color", f, 0)] for f in opt.frame_ids[1:]]
+        if automask:
+            self.noise_rng(target.device)
+        pre = F.photometric_prologue(target, sources, len(opt.scales), noises=None, rng=self._rng, automask=automask)
+        disps = [outputs[("disp", s)].float() for s in opt.scales]
+        smooth = F.smooth_launch(disps, [inputs[("color", 0, s)] for s in opt.scales], need_grad=any(d.requires_grad for d in disps))
+        outputs[("loss_prologue",)] = dict(pre=pre, smooth=smooth)
+
     def compute_loss(self, inputs, outputs, setting):
         opt = self.opt
         target = inputs[("color", 0, 0)]
@@ -317,7 +354,10 @@ class compute(object):
                 elif self.prologue:
                     self.noise_rng(target.device)
             pre = None
-            if self.prologue:
+            early = outputs.pop(("loss_prologue",), None)          # loss_prologue() ran ahead of the pose stream's join
+            if early is not None:
+                pre = early["pre"]
+            elif self.prologue:
                 pre = F.photometric_prologue(target, sources, nsc, noises=noises, rng=self._rng, automask=automask)
             elif automask:
                 ident = F.identity_loss(target, sources)
@@ -335,7 +375,7 @@ class compute(object):
                                    target, sources, inputs[("inv_K", 0)], [inputs[("color", 0, s)] for s in opt.scales],
                                    opt.scales, opt.disp_smoothness, ident, noises if pre is None else None,
                                    automask=automask, min_depth=opt.min_depth, max_depth=opt.max_depth,
-                                   need_depth=(opt.scales[0] == 0), pre=pre)
+                                   need_depth=(opt.scales[0] == 0), pre=pre, smooth=early["smooth"] if early is not None else None)
                 if res["depth"] is not None:
                     outputs[("depth", 0, 0)] = res["depth"]
                 for k, scale in enumerate(opt.scales):

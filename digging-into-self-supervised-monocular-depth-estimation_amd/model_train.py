@@ -240,6 +240,7 @@ class trainer(object):
             with torch.cuda.stream(self._pose_stream):
                 inputs, outputs = self.compute.forward_pose(inputs, outputs, self.setting)
             inputs, outputs = self.compute.forward_depth(inputs, outputs, self.setting)
+            self.compute.loss_prologue(inputs, outputs)       # what the loss needs of the batch and the disparities alone
             cur.wait_stream(self._pose_stream)
         else:
             inputs, outputs = self.compute.forward_depth(inputs, outputs, self.setting)

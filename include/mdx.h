@@ -366,6 +366,20 @@ int mdx_bn_act_nhwc_bwd(const void *dy, const void *dy2, const void *y, const vo
                         const float *beta, const float *save_mean, const float *save_invstd, void *dx, void *dres, float *dgamma,
                         float *dbeta, int B, int C, int H, int W, int groups, int relu, int dtype, void *workspace,
                         size_t workspace_bytes, void *stream);
+/* Between the pose decoder's convolutions   model_layer/pose_decoder.py:24-53 (the convolution runs without its bias).
+ * bias_act: y = act(x + bias), x, y [B][H][W][C] channels-last (dtype 0 float32 / 1 bfloat16, C a multiple of the 16-byte vector),
+ * bias [C] float32, relu 0 / 1.  bwd: dy, y -> dx, dbias [C]: one launch + a finishing pass over the block partials (workspace).
+ * mean_bias: out [B][C] float32 = scale * (mean over H*W of x + bias) -- the head's spatial mean and 0.01 (pose_decoder.py:51-53);
+ * any C.  bwd: gout [B][C] -> dx (x's dtype), dbias [C] (may be NULL). */
+size_t mdx_bias_act_nhwc_workspace_bytes(int B, int C, int H, int W, int dtype);
+int mdx_bias_act_nhwc_fwd(const void *x, const float *bias, void *y, int B, int C, int H, int W, int relu, int dtype, void *stream);
+int mdx_bias_act_nhwc_bwd(const void *dy, const void *y, void *dx, float *dbias, int B, int C, int H, int W, int relu, int dtype,
+                          void *workspace, size_t workspace_bytes, void *stream);
+int mdx_mean_bias_nhwc_fwd(const void *x, const float *bias, float *out, int B, int C, int H, int W, float scale, int dtype,
+                           void *stream);
+int mdx_mean_bias_nhwc_bwd(const float *gout, void *dx, float *dbias, int B, int C, int H, int W, float scale, int dtype,
+                           void *stream);
+
 /* The decoder's disparity heads   model_layer/depth_decoder.py:73-74,108-110: sigmoid(Conv3x3(C -> 1)(x)) on a channels-last map.
  * x [B][h+2][w+2][C] = the reflection-padded input (mdx_decoder_glue_nhwc_fwd's output), dtype 0 float32 / 1 bfloat16, C a
  * power-of-two multiple of the 16-byte vector (4 / 8 elements) up to 64 vectors; weight: float32, element (c, ky, kx) at

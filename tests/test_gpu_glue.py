@@ -474,3 +474,68 @@ def test_decoder_with_fused_heads_equals_miopen_heads():
         assert float((da[s] - db[s]).abs().max()) <= 2e-6, s
     for a, b in zip(ga, gb):
         assert float((a - b).abs().max()) <= 2e-5 * max(1e-30, float(b.abs().max())) + 1e-9
+
+
+@pytest.mark.parametrize("relu", [True, False])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(24, 256, 6, 20), (2, 8, 3, 5), (3, 64, 1, 2), (1, 512, 7, 2), (5, 16, 33, 9)])
+def test_bias_act_matches_torch(F, shape, dtype, relu):
+    """bias_act == relu(x + b) (what follows a pose-decoder convolution that ran without its bias), forward, dx and db."""
+    g = torch.Generator().manual_seed(9)
+    x = _leaf(torch.randn(*shape, generator=g), dtype, True)
+    b = torch.randn(shape[1], generator=g).cuda().requires_grad_(True)
+    gy = torch.randn(*shape, generator=g).to("cuda", dtype).contiguous(memory_format=torch.channels_last)
+    y = F.bias_act(x, b, relu=relu)
+    gx, gb = torch.autograd.grad(y, (x, b), gy)
+    assert _layout_is(y, True) and _layout_is(gx, True) and y.dtype == dtype and gb.dtype == torch.float32
+    xr, br = x.detach().float().requires_grad_(True), b.detach().clone().requires_grad_(True)
+    yr = xr + br.view(1, -1, 1, 1)
+    yr = torch.relu(yr) if relu else yr
+    if dtype == torch.bfloat16:
+        yr = yr.detach().to(dtype).float() + (yr - yr.detach())  # the kernel rounds y once, like this
+    gxr, gbr = torch.autograd.grad(yr, (xr, br), gy.float())
+    assert torch.equal(y.float(), yr.detach()) if dtype == torch.float32 else float((y.float() - yr.detach()).abs().max()) <= 1e-2
+    assert torch.equal(gx.float(), gxr)
+    assert float((gb - gbr).abs().max()) <= 1e-5 * max(1.0, float(gbr.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(24, 12, 6, 20), (2, 6, 1, 2), (3, 12, 5, 7), (4, 64, 3, 3)])
+def test_mean_bias_matches_torch(F, shape, dtype):
+    """mean_bias == 0.01 * (x + b).mean((2, 3)) (pose_decoder.py:51-53), forward, dx and db."""
+    g = torch.Generator().manual_seed(10)
+    x = _leaf(torch.randn(*shape, generator=g), dtype, True)
+    b = torch.randn(shape[1], generator=g).cuda().requires_grad_(True)
+    go = torch.randn(shape[0], shape[1], generator=g).cuda()
+    out = F.mean_bias(x, b, scale=0.01)
+    gx, gb = torch.autograd.grad(out, (x, b), go)
+    xr, br = x.detach().double().requires_grad_(True), b.detach().double().requires_grad_(True)
+    outr = 0.01 * (xr + br.view(1, -1, 1, 1)).mean(dim=(2, 3))
+    gxr, gbr = torch.autograd.grad(outr, (xr, br), go.double())
+    assert out.dtype == torch.float32 and _layout_is(gx, True) and gx.dtype == dtype
+    assert float((out.double() - outr).abs().max()) <= 2e-6 * float(outr.abs().max())
+    assert float((gx.double() - gxr).abs().max()) <= (2e-6 if dtype == torch.float32 else 8e-3) * float(gxr.abs().max())
+    assert float((gb.double() - gbr).abs().max()) <= 2e-6 * float(gbr.abs().max())
+
+
+def test_pose_decoder_fused_tail_equals_torch_ops():
+    """PoseDecoder with bias_act / mean_bias behind bias-free convolutions against the module's plain form."""
+    from model_layer.pose_decoder import PoseDecoder
+    from mdx.layout import apply_plan
+    torch.manual_seed(0)
+    dec = PoseDecoder([64, 64, 128, 256, 512], 1, 2).cuda()
+    apply_plan({"pose_decoder": dec}, "all")
+    feat = torch.randn(6, 512, 6, 20).cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    res = []
+    for fused in (True, False):
+        dec.fused_tail = fused
+        a, t = dec([[feat]])
+        grads = torch.autograd.grad((a * a).sum() + (t * 3.0).sum(), list(dec.parameters()) + [feat])
+        res.append((a.detach(), t.detach(), grads))
+        if fused:
+            assert a._base is not None and a._base is t._base      # what processor._pose_head_output looks for
+    dec.fused_tail = True
+    (a1, t1, g1), (a2, t2, g2) = res
+    assert float((a1 - a2).abs().max()) <= 2e-6 * float(a2.abs().max()) and float((t1 - t2).abs().max()) <= 2e-6 * float(t2.abs().max())
+    for x, y in zip(g1, g2):
+        assert float((x - y).abs().max()) <= 2e-5 * max(1e-30, float(y.abs().max())) + 1e-10
