@@ -237,3 +237,60 @@ MDX_EXPORT int mdx_mean_bias_nhwc_bwd(const float *gout, void *dx, float *dbias,
                            inv, scale, (bf16 *)dx, dbias);
     return check_launch();
 }
+
+// ---- the networks' input: (frame - 0.45) / 0.225 of up to two frames per image, written channels-last ----------------------------
+// depth_encoder.py:89 normalises the input; processor.py:61-75 concatenates the frame pairs of the pose network along the channels
+// (and this package the pairs along the batch); the convolution wants channels-last.  Three concatenations, a subtraction, a
+// multiplication and a layout copy of a [2B][6][H][W] map -- 130 us at the very start of the pose network's chain -- are one pass:
+// out[k * n + b][h][w][3 * g + c] = (src[k][g][b][c][h][w] - mean) * inv_std.
+namespace mdx {
+namespace nhwc {
+
+struct InputSrc { const float *p[4]; };      // [block k][group g] -> p[k * groups + g], planar [n][3][H][W]
+
+template <typename T>
+__global__ __launch_bounds__(NB) void encoder_input_nhwc_kernel(InputSrc src, int blocks, int groups, int n, int HW, float mean, float inv_std,
+                                                                T *__restrict__ out)
+{
+    const long long e = (long long)blockIdx.x * NB + threadIdx.x;          // (image, pixel)
+    if (e >= (long long)blocks * n * HW) return;
+    const int img = (int)(e / HW), pix = (int)(e - (long long)img * HW);
+    const int k = img / n, b = img - k * n;
+    const int C = 3 * groups;
+    T *o = out + (size_t)e * C;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        if (g >= groups) break;
+        const float *s = (k == 0 ? (g == 0 ? src.p[0] : src.p[1]) : (g == 0 ? src.p[groups] : src.p[groups + 1])) + (size_t)b * 3 * HW + pix;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[3 * g + c] = from_float<T>((s[(size_t)c * HW] - mean) * inv_std);
+    }
+}
+
+}  // namespace nhwc
+}  // namespace mdx
+
+// src: HOST array of blocks * groups device pointers, each a planar float32 [n][3][H][W]; out [blocks * n][H][W][3 * groups] in
+// dtype (0 float32 / 1 bfloat16).  inv_std is the float32 reciprocal ATen multiplies by for `/ 0.225`.
+MDX_EXPORT int mdx_encoder_input_nhwc(const float *const *src, int blocks, int groups, int n, int H, int W, float mean, float inv_std,
+                                      void *out, int dtype, void *stream)
+{
+    if (!src || !out) return MDX_ERR_NULL_POINTER;
+    if (blocks < 1 || blocks > 2 || groups < 1 || groups > 2 || n <= 0 || H <= 0 || W <= 0) return MDX_ERR_BAD_SHAPE;
+    if (dtype != PH_F32 && dtype != PH_BF16) return MDX_ERR_BAD_SHAPE;
+    const long long total = (long long)blocks * n * H * W;
+    if (total * 6 >= (1ll << 40)) return MDX_ERR_BAD_SHAPE;
+    InputSrc s = {{nullptr, nullptr, nullptr, nullptr}};
+    for (int i = 0; i < blocks * groups; ++i) {
+        if (!src[i]) return MDX_ERR_NULL_POINTER;
+        s.p[i] = src[i];
+    }
+    const unsigned grid = (unsigned)((total + NB - 1) / NB);
+    if (dtype == PH_F32)
+        hipLaunchKernelGGL((encoder_input_nhwc_kernel<float>), dim3(grid), dim3(NB), 0, (hipStream_t)stream, s, blocks, groups, n, H * W, mean,
+                           inv_std, (float *)out);
+    else
+        hipLaunchKernelGGL((encoder_input_nhwc_kernel<bf16>), dim3(grid), dim3(NB), 0, (hipStream_t)stream, s, blocks, groups, n, H * W, mean,
+                           inv_std, (bf16 *)out);
+    return check_launch();
+}

@@ -870,6 +870,41 @@ def mean_bias(x, bias=None, scale=1.0):
     return _MeanBias.apply(x, bias, float(scale))
 
 
+class FrameStack(object):
+    """torch.cat([torch.cat(block, 1) for block in blocks], 0) of planar [n,3,H,W] frames that nobody has materialised yet: what
+    the step hands the pose encoder for its frame pairs (processor.py:61-75), so that encoder_input can write the normalised,
+    channels-last network input in one pass.  tensor() is the concatenation itself (for a consumer that cannot take the stack)."""
+
+    def __init__(self, blocks):
+        self.blocks = [list(b) for b in blocks]
+
+    def tensor(self):
+        rows = [torch.cat(b, 1) if len(b) > 1 else b[0] for b in self.blocks]
+        return torch.cat(rows, 0) if len(rows) > 1 else rows[0]
+
+    def ok(self):
+        fr = [t for b in self.blocks for t in b]
+        first = fr[0]
+        return (1 <= len(self.blocks) <= 2 and len({len(b) for b in self.blocks}) == 1 and 1 <= len(self.blocks[0]) <= 2
+                and all(t.is_cuda and t.dtype == torch.float32 and t.dim() == 4 and t.shape == first.shape and t.shape[1] == 3
+                        and t.is_contiguous() and not t.requires_grad for t in fr))
+
+
+def encoder_input(stack, mean=0.45, std=0.225, dtype=torch.float32):
+    """(cat(frames) - mean) / std as a channels-last map of `dtype` in one launch (depth_encoder.py:89 behind processor.py:61-75's
+    concatenations).  The division is ATen-GPU's: a multiplication by the float32 reciprocal."""
+    if not stack.ok():
+        raise _lib.MdxError("encoder_input: needs 1-2 blocks of 1-2 planar float32 [n,3,H,W] GPU frames that require no gradient")
+    fr = [t for b in stack.blocks for t in b]
+    n, _, H, W = fr[0].shape
+    blocks, groups = len(stack.blocks), len(stack.blocks[0])
+    out = torch.empty((blocks * n, 3 * groups, H, W), device=fr[0].device, dtype=dtype, memory_format=_CL)
+    inv = float(torch.tensor(1.0, dtype=torch.float32) / torch.tensor(std, dtype=torch.float32))
+    check(lib().mdx_encoder_input_nhwc(_lib.ptr_array(fr), blocks, groups, n, H, W, C.c_float(mean), C.c_float(inv),
+                                       ptr(out, dtype, cl=True), _DTYPE_CODE[dtype], stream()), "mdx_encoder_input_nhwc")
+    return out
+
+
 class _DispHead(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):

@@ -234,10 +234,30 @@ class ResnetEncoder(nn.Module):
         if num_layers > 34:
             self.num_ch_enc[1:] *= 4
 
+    fused_input = True       # False: (x - 0.45) / 0.225 as torch ops on the concatenated frames (A/B, parity tests)
+
+    def _normalised_input(self, input_image):
+        """(x - 0.45) / 0.225 (reference depth_encoder.py:89).  x: a tensor, or the step's not-yet-concatenated frame pairs
+        (mdx.functional.FrameStack).  With a channels-last stem on the GPU the frames go through ONE pass that normalises and
+        writes the channels-last map the first convolution reads (bf16 under autocast: the cast it would do itself)."""
+        from mdx import functional as F
+        from mdx.layout import weight_layout
+        stack = input_image if isinstance(input_image, F.FrameStack) else None
+        if stack is None and torch.is_tensor(input_image) and input_image.dim() == 4 and input_image.shape[1] == 3:
+            stack = F.FrameStack([[input_image]])
+        if (self.fused_input and stack is not None and stack.ok() and weight_layout(self.encoder.conv1)
+                and stack.blocks[0][0].numel() * len(stack.blocks) * len(stack.blocks[0]) < (1 << 31)):
+            dt = torch.get_autocast_gpu_dtype() if torch.is_autocast_enabled() else torch.float32
+            if dt in (torch.float32, torch.bfloat16):
+                return F.encoder_input(stack, 0.45, 0.225, dt)
+        if isinstance(input_image, F.FrameStack):
+            input_image = input_image.tensor()
+        return (input_image - 0.45) / 0.225
+
     def forward(self, input_image):
         from mdx.layout import to_layout, weight_layout
         self.features = []
-        x = (input_image - 0.45) / 0.225
+        x = self._normalised_input(input_image)
         # every map below has two consumers (the next layer's first convolution + its identity path, or the decoder's
         # skip connection + the next layer): producers hand their output on as a pair, see BatchNorm2d.act(fork=True)
         stem, stem_b = _pair(self.encoder.bn1.act(self.encoder.conv1(x), fork=BasicBlock.fork_output))

@@ -198,10 +198,15 @@ class compute(object):
         pairs = []
         for frame_id in frames:
             first, second = (frame_id, 0) if frame_id < 0 else (0, frame_id)
-            pairs.append(torch.cat([inputs[("color_aug", first, 0)], inputs[("color_aug", second, 0)]], 1))
-        n = pairs[0].shape[0]
-        with BatchNorm2d.batch_groups(len(pairs), setting.model["pose_encoder"]):
-            feats = setting.model["pose_encoder"](torch.cat(pairs, 0))
+            pairs.append([inputs[("color_aug", first, 0)], inputs[("color_aug", second, 0)]])
+        n = pairs[0][0].shape[0]
+        # the pairs as they are: the package's encoder normalises and lays them out channels-last in one pass (F.FrameStack);
+        # any other module gets the concatenation
+        stack = F.FrameStack(pairs)
+        encoder = setting.model["pose_encoder"]
+        takes_stack = self.fused_tail and hasattr(getattr(encoder, "module", encoder), "_normalised_input") and stack.ok()
+        with BatchNorm2d.batch_groups(len(pairs), encoder):
+            feats = encoder(stack if takes_stack else stack.tensor())
         axisangle, translation = setting.model["pose_decoder"]([feats])
         for k, frame_id in enumerate(frames):
             outputs[("R", frame_id, 0)] = axisangle[k * n:(k + 1) * n]

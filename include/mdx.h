@@ -380,6 +380,13 @@ int mdx_mean_bias_nhwc_fwd(const void *x, const float *bias, float *out, int B, 
 int mdx_mean_bias_nhwc_bwd(const float *gout, void *dx, float *dbias, int B, int C, int H, int W, float scale, int dtype,
                            void *stream);
 
+/* The networks' input   depth_encoder.py:89 ((x - 0.45) / 0.225) + processor.py:61-75 (the pose network's frame pairs concatenated
+ * along the channels; this package: the pairs along the batch) written channels-last in one pass.  src: HOST array of
+ * blocks * groups (1..2 each) device pointers, src[k * groups + g] a planar float32 [n][3][H][W] frame;
+ * out [blocks * n][H][W][3 * groups] (dtype 0 float32 / 1 bfloat16) = (src - mean) * inv_std. */
+int mdx_encoder_input_nhwc(const float *const *src, int blocks, int groups, int n, int H, int W, float mean, float inv_std,
+                           void *out, int dtype, void *stream);
+
 /* The decoder's disparity heads   model_layer/depth_decoder.py:73-74,108-110: sigmoid(Conv3x3(C -> 1)(x)) on a channels-last map.
  * x [B][h+2][w+2][C] = the reflection-padded input (mdx_decoder_glue_nhwc_fwd's output), dtype 0 float32 / 1 bfloat16, C a
  * power-of-two multiple of the 16-byte vector (4 / 8 elements) up to 64 vectors; weight: float32, element (c, ky, kx) at
