@@ -54,6 +54,7 @@ SYMBOLS = {
     "mdx_reprojection_loss_fwd": C.c_int, "mdx_reprojection_loss_bwd": C.c_int, "mdx_ssim_fwd": C.c_int, "mdx_ssim_bwd": C.c_int,
     "mdx_min_automask_fwd": C.c_int,
     "mdx_loss_total_fwd": C.c_int, "mdx_loss_total_bwd": C.c_int,
+    "mdx_adam_max_tensors": C.c_int, "mdx_adam_chunk": C.c_int, "mdx_adam_table_entry_bytes": C.c_size_t, "mdx_adam_step": C.c_int,
     "mdx_pose_projection_fwd": C.c_int, "mdx_pose_projection_bwd": C.c_int,
     "mdx_bias_act_nhwc_workspace_bytes": C.c_size_t, "mdx_bias_act_nhwc_fwd": C.c_int, "mdx_bias_act_nhwc_bwd": C.c_int,
     "mdx_mean_bias_nhwc_fwd": C.c_int, "mdx_mean_bias_nhwc_bwd": C.c_int, "mdx_encoder_input_nhwc": C.c_int,

@@ -151,8 +151,12 @@ class setting(object):
 
     # reference: loader.py:106-109
     def set_optim(self):
-        fused = str(self.device).startswith("cuda")
-        self.optim["optimizer"] = torch.optim.Adam(self.parameters, float(self.opt.learning_rate), fused=fused)
+        if str(self.device).startswith("cuda") and _opt(self.opt, "native_adam", True):
+            from mdx.optim import Adam             # torch.optim.Adam(fused=True) with its step as one launch (csrc/adam.hip)
+            self.optim["optimizer"] = Adam(self.parameters, float(self.opt.learning_rate))
+        else:
+            fused = str(self.device).startswith("cuda")
+            self.optim["optimizer"] = torch.optim.Adam(self.parameters, float(self.opt.learning_rate), fused=fused)
         self.optim["scheduler"] = torch.optim.lr_scheduler.StepLR(self.optim["optimizer"], self.opt.scheduler_step)
 
     def set_train(self):

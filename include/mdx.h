@@ -229,6 +229,19 @@ int mdx_loss_total_bwd(int nscales, const float *g_total, const int32_t *scale, 
                        const float *const *gd_photo, const float *const *gd_smooth, const int64_t *count,
                        float *const *gdisp, const float *gP, int nP, int per_scale_P, float *gP_out, void *stream);
 
+/* The optimiser step   reference model_tool/loader.py:93-97 (torch.optim.Adam, no weight decay / amsgrad / maximize) in ONE launch
+ * for every parameter of a group.  table: DEVICE array of { float *param, *exp_avg, *exp_avg_sq; const float *step; int64_t numel }
+ * (mdx_adam_table_entry_bytes() each; step = the tensor's float32 step count, already incremented); one call takes entries
+ * first .. first + count - 1, count <= mdx_adam_max_tensors(); grads: HOST array of count device pointers (they change from step
+ * to step); blockmap: DEVICE array of nblocks { int32 tensor (0-based within the call), int32 chunk } covering every tensor in
+ * chunks of mdx_adam_chunk() elements; lr_ptr: device float32 (a captured step's learning rate) or NULL (then lr).
+ * Arithmetic: ATen's fused Adam, expression by expression (ATen/native/cuda/fused_adam_utils.cuh). */
+int mdx_adam_max_tensors(void);
+int mdx_adam_chunk(void);
+size_t mdx_adam_table_entry_bytes(void);
+int mdx_adam_step(const void *table, int first, int count, const float *const *grads, const void *blockmap, int nblocks,
+                  const float *lr_ptr, double lr, double beta1, double beta2, double eps, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Fine-grained ops behind the reference's model_layer / model_loss API (each differentiable)
  * ---------------------------------------------------------------------------------------- */

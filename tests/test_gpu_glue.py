@@ -518,29 +518,45 @@ def test_mean_bias_matches_torch(F, shape, dtype):
     assert float((gb.double() - gbr).abs().max()) <= 2e-6 * float(gbr.abs().max())
 
 
-def test_pose_decoder_fused_tail_equals_torch_ops():
-    """PoseDecoder with bias_act / mean_bias behind bias-free convolutions against the module's plain form."""
+def test_pose_decoder_fused_tail_equals_torch_ops(monkeypatch):
+    """PoseDecoder with bias_act / mean_bias behind bias-free convolutions against the module's plain form.  Gradients are
+    compared on an input for which every ReLU takes the same branch in both forms: a pre-activation within the 2e-7 rounding
+    difference of the kink takes the other one, and its whole gradient with it (about one input in five has such an element)."""
     from model_layer.pose_decoder import PoseDecoder
     from mdx.layout import apply_plan
     torch.manual_seed(0)
     dec = PoseDecoder([64, 64, 128, 256, 512], 1, 2).cuda()
     apply_plan({"pose_decoder": dec}, "all")
-    feat = torch.randn(6, 512, 6, 20).cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
-    res = []
-    for fused in (True, False):
-        dec.fused_tail = fused
-        a, t = dec([[feat]])
-        grads = torch.autograd.grad((a * a).sum() + (t * 3.0).sum(), list(dec.parameters()) + [feat])
-        res.append((a.detach(), t.detach(), grads))
-        if fused:
-            assert a._base is not None and a._base is t._base      # what processor._pose_head_output looks for
+    acts = []
+    plain = PoseDecoder._conv
+
+    def spy(self, k, x, relu=True):
+        y = plain(self, k, x, relu)
+        acts.append(y.detach() > 0)
+        return y
+    monkeypatch.setattr(PoseDecoder, "_conv", spy)
+    for seed in range(20):
+        g = torch.Generator().manual_seed(seed)
+        feat = torch.randn(6, 512, 6, 20, generator=g).cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        res, masks = [], []
+        for fused in (True, False):
+            dec.fused_tail = fused
+            del acts[:]
+            a, t = dec([[feat]])
+            masks.append(list(acts))
+            grads = torch.autograd.grad((a * a).sum() + (t * 3.0).sum(), list(dec.parameters()) + [feat])
+            res.append((a.detach(), t.detach(), grads))
+            if fused:
+                assert a._base is not None and a._base is t._base      # what processor._pose_head_output looks for
+        (a1, t1, g1), (a2, t2, g2) = res
+        assert float((a1 - a2).abs().max()) <= 2e-6 * float(a2.abs().max()) and float((t1 - t2).abs().max()) <= 2e-6 * float(t2.abs().max())
+        if all(torch.equal(u, v) for u, v in zip(*masks)):
+            break
+    else:
+        pytest.fail("twenty inputs in a row with a ReLU at its kink")
     dec.fused_tail = True
-    (a1, t1, g1), (a2, t2, g2) = res
-    assert float((a1 - a2).abs().max()) <= 2e-6 * float(a2.abs().max()) and float((t1 - t2).abs().max()) <= 2e-6 * float(t2.abs().max())
-    # the weight gradients are sums of ~1e3 terms of both signs two orders above their result, and MIOpen picks other kernels for a
-    # convolution without a bias: agreement to the cancellation noise of a float32 sum, not to an ulp
     for x, y in zip(g1, g2):
-        assert float((x - y).abs().max()) <= 5e-3 * max(1e-30, float(y.abs().max())) + 1e-10
+        assert float((x - y).abs().max()) <= 2e-5 * max(1e-30, float(y.abs().max())) + 1e-10
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
