@@ -52,10 +52,9 @@ __global__ __launch_bounds__(NB) void bias_act_nhwc_bwd_kernel(const T *__restri
 #pragma unroll
     for (int j = 0; j < N; ++j) a[j] = 0.f;
     if (p.active) {
-        const T *pd = dy + (size_t)p.cv * N, *py = y + (size_t)p.cv * N;
-        T *ox = dx + (size_t)p.cv * N;
-        for (int r = p.r0 + p.pl; r < p.r1; r += PL) {
-            const Vec<T, N> d = load_vec<T, N>(pd + (size_t)r * C), v = load_vec<T, N>(py + (size_t)r * C);
+        const T *__restrict__ pd = dy + (size_t)p.cv * N, *__restrict__ py = y + (size_t)p.cv * N;
+        T *__restrict__ ox = dx + (size_t)p.cv * N;
+        auto one = [&](const Vec<T, N> &d, const Vec<T, N> &v, size_t off) {
             Vec<T, N> w;
 #pragma unroll
             for (int j = 0; j < N; ++j) {
@@ -63,8 +62,16 @@ __global__ __launch_bounds__(NB) void bias_act_nhwc_bwd_kernel(const T *__restri
                 a[j] += dz;
                 w.v[j] = from_float<T>(dz);
             }
-            store_vec<T, N>(ox + (size_t)r * C, w);
+            store_vec<T, N>(ox + off, w);
+        };
+        int r = p.r0 + p.pl;
+        for (; r + 3 * PL < p.r1; r += 4 * PL) {          // every load of four rows before the first store
+            const size_t o0 = (size_t)r * C, o1 = (size_t)(r + PL) * C, o2 = (size_t)(r + 2 * PL) * C, o3 = (size_t)(r + 3 * PL) * C;
+            const Vec<T, N> d0 = load_vec<T, N>(pd + o0), d1 = load_vec<T, N>(pd + o1), d2 = load_vec<T, N>(pd + o2), d3 = load_vec<T, N>(pd + o3);
+            const Vec<T, N> v0 = load_vec<T, N>(py + o0), v1 = load_vec<T, N>(py + o1), v2 = load_vec<T, N>(py + o2), v3 = load_vec<T, N>(py + o3);
+            one(d0, v0, o0); one(d1, v1, o1); one(d2, v2, o2); one(d3, v3, o3);
         }
+        for (; r < p.r1; r += PL) one(load_vec<T, N>(pd + (size_t)r * C), load_vec<T, N>(py + (size_t)r * C), (size_t)r * C);
     }
 #pragma unroll
     for (int j = 0; j < N; ++j) lds[threadIdx.x * N + j] = a[j];
@@ -246,25 +253,29 @@ MDX_EXPORT int mdx_mean_bias_nhwc_bwd(const float *gout, void *dx, float *dbias,
 namespace mdx {
 namespace nhwc {
 
-struct InputSrc { const float *p[4]; };      // [block k][group g] -> p[k * groups + g], planar [n][3][H][W]
+struct InputSrc { const float *p[4]; };      // [block k][group g] -> p[2 * k + g], planar [n][3][H][W]
 
 template <typename T>
-__global__ __launch_bounds__(NB) void encoder_input_nhwc_kernel(InputSrc src, int blocks, int groups, int n, int HW, float mean, float inv_std,
+__global__ __launch_bounds__(NB) void encoder_input_nhwc_kernel(InputSrc src, int groups, int n, int HW, float mean, float inv_std,
                                                                 T *__restrict__ out)
 {
-    const long long e = (long long)blockIdx.x * NB + threadIdx.x;          // (image, pixel)
-    if (e >= (long long)blocks * n * HW) return;
-    const int img = (int)(e / HW), pix = (int)(e - (long long)img * HW);
-    const int k = img / n, b = img - k * n;
+    // grid (ceil(HW / NB), images): no division, every index in 32 bits
+    const int pix = blockIdx.x * NB + threadIdx.x, img = blockIdx.y;
+    if (pix >= HW) return;
+    const int k = img >= n ? 1 : 0, b = img - k * n;
     const int C = 3 * groups;
-    T *o = out + (size_t)e * C;
+    float v[6];
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         if (g >= groups) break;
-        const float *s = (k == 0 ? (g == 0 ? src.p[0] : src.p[1]) : (g == 0 ? src.p[groups] : src.p[groups + 1])) + (size_t)b * 3 * HW + pix;
+        const float *__restrict__ s = (k == 0 ? (g == 0 ? src.p[0] : src.p[1]) : (g == 0 ? src.p[2] : src.p[3])) + (size_t)b * 3 * HW + pix;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) o[3 * g + c] = from_float<T>((s[(size_t)c * HW] - mean) * inv_std);
+        for (int c = 0; c < 3; ++c) v[3 * g + c] = (s[(size_t)c * HW] - mean) * inv_std;
     }
+    T *o = out + ((size_t)img * HW + pix) * C;
+#pragma unroll
+    for (int c = 0; c < 6; ++c)
+        if (c < C) o[c] = from_float<T>(v[c]);
 }
 
 }  // namespace nhwc
@@ -281,16 +292,18 @@ MDX_EXPORT int mdx_encoder_input_nhwc(const float *const *src, int blocks, int g
     const long long total = (long long)blocks * n * H * W;
     if (total * 6 >= (1ll << 40)) return MDX_ERR_BAD_SHAPE;
     InputSrc s = {{nullptr, nullptr, nullptr, nullptr}};
-    for (int i = 0; i < blocks * groups; ++i) {
-        if (!src[i]) return MDX_ERR_NULL_POINTER;
-        s.p[i] = src[i];
-    }
-    const unsigned grid = (unsigned)((total + NB - 1) / NB);
+    for (int k = 0; k < blocks; ++k)
+        for (int g = 0; g < groups; ++g) {
+            if (!src[k * groups + g]) return MDX_ERR_NULL_POINTER;
+            s.p[2 * k + g] = src[k * groups + g];               // [block][group], two slots per block
+        }
+    if ((long long)H * W >= (1ll << 31) || blocks * n > 65535) return MDX_ERR_BAD_SHAPE;
+    const dim3 grid((unsigned)(((long long)H * W + NB - 1) / NB), (unsigned)(blocks * n));
     if (dtype == PH_F32)
-        hipLaunchKernelGGL((encoder_input_nhwc_kernel<float>), dim3(grid), dim3(NB), 0, (hipStream_t)stream, s, blocks, groups, n, H * W, mean,
-                           inv_std, (float *)out);
+        hipLaunchKernelGGL((encoder_input_nhwc_kernel<float>), grid, dim3(NB), 0, (hipStream_t)stream, s, groups, n, H * W, mean, inv_std,
+                           (float *)out);
     else
-        hipLaunchKernelGGL((encoder_input_nhwc_kernel<bf16>), dim3(grid), dim3(NB), 0, (hipStream_t)stream, s, blocks, groups, n, H * W, mean,
-                           inv_std, (bf16 *)out);
+        hipLaunchKernelGGL((encoder_input_nhwc_kernel<bf16>), grid, dim3(NB), 0, (hipStream_t)stream, s, groups, n, H * W, mean, inv_std,
+                           (bf16 *)out);
     return check_launch();
 }
