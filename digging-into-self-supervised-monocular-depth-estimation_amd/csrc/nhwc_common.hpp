@@ -18,12 +18,10 @@ template <typename T> __device__ __forceinline__ T from_float(float x);
 template <> __device__ __forceinline__ float from_float<float>(float x) { return x; }
 template <> __device__ __forceinline__ bf16 from_float<bf16>(float x)
 {
-    // round to nearest even, NaN stays NaN (torch's float -> bfloat16)
-    uint32_t u = __float_as_uint(x);
+    // round to nearest even, NaN stays NaN (torch's float -> bfloat16): gfx950's v_cvt_pk_bf16_f32 -- one instruction where the
+    // integer sequence (NaN test, rounding add, shift) took six, which made the bfloat16 apply passes VALU-bound
     bf16 r;
-    if ((u & 0x7fffffffu) > 0x7f800000u) { r.v = (uint16_t)((u >> 16) | 0x40u); return r; }
-    u += 0x7fffu + ((u >> 16) & 1u);
-    r.v = (uint16_t)(u >> 16);
+    r.v = __builtin_bit_cast(uint16_t, (__bf16)x);
     return r;
 }
 

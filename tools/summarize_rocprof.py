@@ -10,6 +10,31 @@ import os
 import sys
 
 
+FAMILIES = (("miopen conv:fwd", ("igemm_fwd", "conv_fwd", "ConvFwd")), ("miopen conv:bwd", ("igemm_bwd", "conv_bwd_data", "ConvBwd")),
+            ("miopen conv:wrw", ("igemm_wrw", "conv_bwd_weight", "ConvWrw")), ("miopen zero-fill", ("SubTensorOpWithScalar",)),
+            ("mdx:bn_", ("bn_nhwc", "bn_act", "mdx::bn_")), ("mdx:decoder_glue", ("decoder_glue",)), ("mdx:maxpool", ("maxpool3s2",)),
+            ("mdx:disp_head", ("disp_head",)), ("mdx:pose head / input", ("bias_act", "mean_bias", "colsum_scale", "encoder_input",
+                                                                      "pose_projection", "param2matrix", "compose_projection")),
+            ("mdx:loss path", ("photometric", "smooth_multi", "train_finish", "loss_total")), ("mdx:adam", ("adam_step",)),
+            ("mdx:other", ("mdx::",)))
+
+
+def families(rows):
+    """kernel time and launches per family and per step (a step = one launch of the training kernel)."""
+    steps = sum(int(r["Calls"]) for r in rows if "photometric_train_kernel" in r["Name"]) or 1
+    acc = {}
+    for r in rows:
+        fam = next((f for f, keys in FAMILIES if any(k in r["Name"] for k in keys)), "aten / other")
+        t, n = acc.get(fam, (0.0, 0))
+        acc[fam] = (t + float(r["TotalDurationNs"]), n + int(r["Calls"]))
+    tot = sum(t for t, _ in acc.values())
+    out = ["# per family, per step (%d steps profiled; under the profiler the two networks' kernels run one after the other)  total %.2f ms/step"
+           % (steps, tot / steps / 1e6)]
+    for fam, (t, n) in sorted(acc.items(), key=lambda kv: -kv[1][0]):
+        out.append("#   %-26s %8.3f ms/step %6.1f %% %8.1f calls/step" % (fam, t / steps / 1e6, 100 * t / tot, n / steps))
+    return out
+
+
 def main():
     src, dst = sys.argv[1], sys.argv[2]
     cmd = sys.argv[3] if len(sys.argv) > 3 else ""
@@ -28,6 +53,7 @@ def main():
             lines.append("%-92s %7s %11.3f %10.2f %10.2f %10.2f %6.2f" % (
                 r["Name"][:92], r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3,
                 float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, 100 * float(r["TotalDurationNs"]) / tot))
+    lines += families(rows)
     open(dst, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines[:24]))
 
