@@ -136,8 +136,10 @@ __global__ __launch_bounds__(FC *FS) void bn_nhwc_fwd_finalize_kernel(const floa
     if (writer && run_mean) { run_mean[c] = rm; run_var[c] = rv; }
 }
 
-// backward: totals[g][2][C] = (sum dz, sum dz * xhat) per group; d(beta), d(gamma) = their sums over the groups
-__global__ __launch_bounds__(FC *FS) void bn_nhwc_bwd_finalize_kernel(const float *__restrict__ part, int nblk, int C, int G,
+// backward: totals[g][2][C] = the MEANS over the M rows of (dz, dz * xhat) per group -- what the apply pass subtracts: formed here,
+// once per channel, not by every thread of the apply pass (two float64 divisions per channel of its vector in front of four rows of
+// work); d(beta), d(gamma) = the sums over the groups
+__global__ __launch_bounds__(FC *FS) void bn_nhwc_bwd_finalize_kernel(const float *__restrict__ part, int nblk, int C, int G, double M,
                                                                        float *__restrict__ totals, float *__restrict__ dgamma,
                                                                        float *__restrict__ dbeta)
 {
@@ -149,8 +151,8 @@ __global__ __launch_bounds__(FC *FS) void bn_nhwc_bwd_finalize_kernel(const floa
         double a, q;
         channel_totals(part + (size_t)g * nblk * 2 * C, nblk, C, c, lds, a, q);
         if (writer) {
-            totals[((size_t)g * 2 + 0) * C + c] = (float)a;
-            totals[((size_t)g * 2 + 1) * C + c] = (float)q;
+            totals[((size_t)g * 2 + 0) * C + c] = (float)((double)(float)a / M);
+            totals[((size_t)g * 2 + 1) * C + c] = (float)((double)(float)q / M);
             sa += (float)a;
             sq += (float)q;
         }
@@ -290,8 +292,8 @@ __global__ __launch_bounds__(NB) void bn_nhwc_bwd_apply_kernel(const T *__restri
         invstd[j] = save_invstd[(size_t)p.g * C + c];
         k0[j] = gamma[c] * invstd[j];                      // = the forward pass's scale
         shift[j] = (!y && relu) ? beta[c] - mean[j] * k0[j] : 0.f;
-        mdz[j] = (float)((double)totals[((size_t)p.g * 2 + 0) * C + c] / (double)M);
-        mdzx[j] = (float)((double)totals[((size_t)p.g * 2 + 1) * C + c] / (double)M);
+        mdz[j] = totals[((size_t)p.g * 2 + 0) * C + c];
+        mdzx[j] = totals[((size_t)p.g * 2 + 1) * C + c];
     }
     const size_t base = (size_t)p.g * M * C + (size_t)p.cv * N;
     const T *pd = dy + base, *pd2 = dy2 ? dy2 + base : nullptr, *py = y ? y + base : nullptr, *px = x + base;
@@ -420,7 +422,7 @@ MDX_EXPORT int mdx_bn_act_nhwc_bwd(const void *dy, const void *dy2, const void *
     else
         hipLaunchKernelGGL((bn_nhwc_bwd_stats_kernel<bf16>), grid_s, block, 0, st, (const bf16 *)dy, (const bf16 *)dy2,
                            (const bf16 *)y, (const bf16 *)x, gamma, beta, save_mean, save_invstd, M, C, gs.t.CVB, gs.t.PL, gs.RB, relu, part);
-    hipLaunchKernelGGL(bn_nhwc_bwd_finalize_kernel, dim3((C + FC - 1) / FC), dim3(FC * FS), 0, st, part, gs.nblk, C, groups, totals,
+    hipLaunchKernelGGL(bn_nhwc_bwd_finalize_kernel, dim3((C + FC - 1) / FC), dim3(FC * FS), 0, st, part, gs.nblk, C, groups, (double)M, totals,
                        dgamma, dbeta);
     if (dtype == 0)
         hipLaunchKernelGGL((bn_nhwc_bwd_apply_kernel<float>), grid_a, block, 0, st, (const float *)dy, (const float *)dy2,
