@@ -209,7 +209,9 @@ __global__ __launch_bounds__(NB) void bn_nhwc_fwd_apply_kernel(const T *__restri
 }
 
 // ---- backward, pass 1 ---------------------------------------------------------------------------------------------
-template <typename T>
+// MASKX: the ReLU mask is re-derived from x (y == nullptr) -- a separate instantiation, so that the form that reads y carries neither
+// its registers nor its branches (as ONE kernel the bfloat16 apply pass went from 31 to 56 us per call)
+template <typename T, bool MASKX>
 __global__ __launch_bounds__(NB) void bn_nhwc_bwd_stats_kernel(const T *__restrict__ dy, const T *__restrict__ dy2,
                                                                const T *__restrict__ y, const T *__restrict__ x,
                                                                const float *__restrict__ gamma, const float *__restrict__ beta,
@@ -230,19 +232,19 @@ __global__ __launch_bounds__(NB) void bn_nhwc_bwd_stats_kernel(const T *__restri
             mean[j] = save_mean[(size_t)p.g * C + p.cv * N + j];
             invstd[j] = save_invstd[(size_t)p.g * C + p.cv * N + j];
             scale[j] = shift[j] = 0.f;
-            if (!y && relu) {          // the forward pass's own expressions (bn_nhwc_fwd_apply_kernel): y is re-derived, not read
+            if (MASKX) {               // the forward pass's own expressions (bn_nhwc_fwd_apply_kernel): y is re-derived, not read
                 scale[j] = gamma[p.cv * N + j] * invstd[j];
                 shift[j] = beta[p.cv * N + j] - mean[j] * scale[j];
             }
         }
         const size_t base = (size_t)p.g * M * C + (size_t)p.cv * N;
-        const T *pd = dy + base, *pd2 = dy2 ? dy2 + base : nullptr, *py = y ? y + base : nullptr, *px = x + base;
+        const T *pd = dy + base, *pd2 = dy2 ? dy2 + base : nullptr, *py = MASKX ? nullptr : y + base, *px = x + base;
         auto acc = [&](const Vec<T, N> &vd, const Vec<T, N> &vd2, const Vec<T, N> &vy, const Vec<T, N> &vx) {
 #pragma unroll
             for (int j = 0; j < N; ++j) {
                 float d = to_float(vd.v[j]);
                 if (pd2) d += to_float(vd2.v[j]);
-                const float yv = py ? to_float(vy.v[j]) : to_float(from_float<T>(__builtin_fmaf(to_float(vx.v[j]), scale[j], shift[j])));
+                const float yv = !MASKX ? to_float(vy.v[j]) : to_float(from_float<T>(__builtin_fmaf(to_float(vx.v[j]), scale[j], shift[j])));
                 const float dz = (relu && !(yv > 0.f)) ? 0.f : d;
                 a[j] += dz;
                 q[j] = __builtin_fmaf(dz, (to_float(vx.v[j]) - mean[j]) * invstd[j], q[j]);
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(NB) void bn_nhwc_bwd_stats_kernel(const T *__restri
             const size_t o0 = (size_t)r * C, o1 = (size_t)(r + PL) * C;
             const Vec<T, N> d0 = load_vec<T, N>(pd + o0), d1 = load_vec<T, N>(pd + o1);
             Vec<T, N> y0 = {}, y1 = {};
-            if (py) { y0 = load_vec<T, N>(py + o0); y1 = load_vec<T, N>(py + o1); }
+            if (!MASKX) { y0 = load_vec<T, N>(py + o0); y1 = load_vec<T, N>(py + o1); }
             const Vec<T, N> x0 = load_vec<T, N>(px + o0), x1 = load_vec<T, N>(px + o1);
             Vec<T, N> e0 = {}, e1 = {};
             if (pd2) { e0 = load_vec<T, N>(pd2 + o0); e1 = load_vec<T, N>(pd2 + o1); }
@@ -264,7 +266,7 @@ __global__ __launch_bounds__(NB) void bn_nhwc_bwd_stats_kernel(const T *__restri
             const size_t o = (size_t)r * C;
             Vec<T, N> e = {}, yv = {};
             if (pd2) e = load_vec<T, N>(pd2 + o);
-            if (py) yv = load_vec<T, N>(py + o);
+            if (!MASKX) yv = load_vec<T, N>(py + o);
             acc(load_vec<T, N>(pd + o), e, yv, load_vec<T, N>(px + o));
         }
     }
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(NB) void bn_nhwc_bwd_stats_kernel(const T *__restri
 }
 
 // ---- backward, pass 2 ---------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool MASKX>
 __global__ __launch_bounds__(NB) void bn_nhwc_bwd_apply_kernel(const T *__restrict__ dy, const T *__restrict__ dy2,
                                                                const T *__restrict__ y, const T *__restrict__ x,
                                                                const float *__restrict__ gamma, const float *__restrict__ beta,
@@ -291,12 +293,12 @@ __global__ __launch_bounds__(NB) void bn_nhwc_bwd_apply_kernel(const T *__restri
         mean[j] = save_mean[(size_t)p.g * C + c];
         invstd[j] = save_invstd[(size_t)p.g * C + c];
         k0[j] = gamma[c] * invstd[j];                      // = the forward pass's scale
-        shift[j] = (!y && relu) ? beta[c] - mean[j] * k0[j] : 0.f;
+        shift[j] = MASKX ? beta[c] - mean[j] * k0[j] : 0.f;
         mdz[j] = totals[((size_t)p.g * 2 + 0) * C + c];
         mdzx[j] = totals[((size_t)p.g * 2 + 1) * C + c];
     }
     const size_t base = (size_t)p.g * M * C + (size_t)p.cv * N;
-    const T *pd = dy + base, *pd2 = dy2 ? dy2 + base : nullptr, *py = y ? y + base : nullptr, *px = x + base;
+    const T *pd = dy + base, *pd2 = dy2 ? dy2 + base : nullptr, *py = MASKX ? nullptr : y + base, *px = x + base;
     T *ox = dx + base;
     T *orr = dres ? dres + base : nullptr;
     auto apply = [&](const Vec<T, N> &vd, const Vec<T, N> &vd2, const Vec<T, N> &vy, const Vec<T, N> &vx, size_t off) {
@@ -305,7 +307,7 @@ __global__ __launch_bounds__(NB) void bn_nhwc_bwd_apply_kernel(const T *__restri
         for (int j = 0; j < N; ++j) {
             float d = to_float(vd.v[j]);
             if (pd2) d += to_float(vd2.v[j]);
-            const float yv = py ? to_float(vy.v[j]) : to_float(from_float<T>(__builtin_fmaf(to_float(vx.v[j]), k0[j], shift[j])));
+            const float yv = !MASKX ? to_float(vy.v[j]) : to_float(from_float<T>(__builtin_fmaf(to_float(vx.v[j]), k0[j], shift[j])));
             const float dz = (relu && !(yv > 0.f)) ? 0.f : d;
             const float xh = (to_float(vx.v[j]) - mean[j]) * invstd[j];
             wx.v[j] = from_float<T>(k0[j] * (dz - mdz[j] - xh * mdzx[j]));
@@ -319,7 +321,7 @@ __global__ __launch_bounds__(NB) void bn_nhwc_bwd_apply_kernel(const T *__restri
         const size_t o0 = (size_t)r * C, o1 = (size_t)(r + PL) * C;
         const Vec<T, N> d0 = load_vec<T, N>(pd + o0), d1 = load_vec<T, N>(pd + o1);
         Vec<T, N> y0 = {}, y1 = {};
-        if (py) { y0 = load_vec<T, N>(py + o0); y1 = load_vec<T, N>(py + o1); }
+        if (!MASKX) { y0 = load_vec<T, N>(py + o0); y1 = load_vec<T, N>(py + o1); }
         const Vec<T, N> x0 = load_vec<T, N>(px + o0), x1 = load_vec<T, N>(px + o1);
         Vec<T, N> e0 = {}, e1 = {};
         if (pd2) { e0 = load_vec<T, N>(pd2 + o0); e1 = load_vec<T, N>(pd2 + o1); }
@@ -330,7 +332,7 @@ __global__ __launch_bounds__(NB) void bn_nhwc_bwd_apply_kernel(const T *__restri
         const size_t o = (size_t)r * C;
         Vec<T, N> e = {}, yv = {};
         if (pd2) e = load_vec<T, N>(pd2 + o);
-        if (py) yv = load_vec<T, N>(py + o);
+        if (!MASKX) yv = load_vec<T, N>(py + o);
         apply(load_vec<T, N>(pd + o), e, yv, load_vec<T, N>(px + o), o);
     }
 }
@@ -403,7 +405,7 @@ MDX_EXPORT int mdx_bn_act_nhwc_bwd(const void *dy, const void *dy2, const void *
 {
     if (!dy || !x || !gamma || !save_mean || !save_invstd || !dx || !dgamma || !dbeta || !workspace)
         return MDX_ERR_NULL_POINTER;
-    if (!y && relu && (!beta || dres)) return MDX_ERR_NULL_POINTER;     // without y the mask needs beta, and there is no residual
+    if (!y && (!relu || !beta || dres)) return MDX_ERR_NULL_POINTER;    // y may be left out only for relu without a residual, and then the mask needs beta
     const int bad = nhwc_args_ok(B, C, H, W, groups, dtype);
     if (bad) return bad;
     if (!aligned(dy, 16) || (y && !aligned(y, 16)) || !aligned(x, 16) || !aligned(dx, 16) || (dy2 && !aligned(dy2, 16)) ||
@@ -416,21 +418,34 @@ MDX_EXPORT int mdx_bn_act_nhwc_bwd(const void *dy, const void *dy2, const void *
     float *totals = part + (size_t)groups * gs.nblk * 2 * C;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid_s(gs.nblk, gs.t.ny, groups), grid_a(ga.nblk, ga.t.ny, groups), block(NB);
-    if (dtype == 0)
-        hipLaunchKernelGGL((bn_nhwc_bwd_stats_kernel<float>), grid_s, block, 0, st, (const float *)dy, (const float *)dy2,
-                           (const float *)y, (const float *)x, gamma, beta, save_mean, save_invstd, M, C, gs.t.CVB, gs.t.PL, gs.RB, relu, part);
+    const bool maskx = !y;              // (checked above: only with relu, beta and no residual)
+#define MDX_BN_BWD(KERNEL, T, MX, ...) hipLaunchKernelGGL((KERNEL<T, MX>), __VA_ARGS__)
+    if (dtype == 0 && maskx)
+        MDX_BN_BWD(bn_nhwc_bwd_stats_kernel, float, true, grid_s, block, 0, st, (const float *)dy, (const float *)dy2, (const float *)y,
+                   (const float *)x, gamma, beta, save_mean, save_invstd, M, C, gs.t.CVB, gs.t.PL, gs.RB, relu, part);
+    else if (dtype == 0)
+        MDX_BN_BWD(bn_nhwc_bwd_stats_kernel, float, false, grid_s, block, 0, st, (const float *)dy, (const float *)dy2, (const float *)y,
+                   (const float *)x, gamma, beta, save_mean, save_invstd, M, C, gs.t.CVB, gs.t.PL, gs.RB, relu, part);
+    else if (maskx)
+        MDX_BN_BWD(bn_nhwc_bwd_stats_kernel, bf16, true, grid_s, block, 0, st, (const bf16 *)dy, (const bf16 *)dy2, (const bf16 *)y,
+                   (const bf16 *)x, gamma, beta, save_mean, save_invstd, M, C, gs.t.CVB, gs.t.PL, gs.RB, relu, part);
     else
-        hipLaunchKernelGGL((bn_nhwc_bwd_stats_kernel<bf16>), grid_s, block, 0, st, (const bf16 *)dy, (const bf16 *)dy2,
-                           (const bf16 *)y, (const bf16 *)x, gamma, beta, save_mean, save_invstd, M, C, gs.t.CVB, gs.t.PL, gs.RB, relu, part);
+        MDX_BN_BWD(bn_nhwc_bwd_stats_kernel, bf16, false, grid_s, block, 0, st, (const bf16 *)dy, (const bf16 *)dy2, (const bf16 *)y,
+                   (const bf16 *)x, gamma, beta, save_mean, save_invstd, M, C, gs.t.CVB, gs.t.PL, gs.RB, relu, part);
     hipLaunchKernelGGL(bn_nhwc_bwd_finalize_kernel, dim3((C + FC - 1) / FC), dim3(FC * FS), 0, st, part, gs.nblk, C, groups, (double)M, totals,
                        dgamma, dbeta);
-    if (dtype == 0)
-        hipLaunchKernelGGL((bn_nhwc_bwd_apply_kernel<float>), grid_a, block, 0, st, (const float *)dy, (const float *)dy2,
-                           (const float *)y, (const float *)x, gamma, beta, save_mean, save_invstd, totals, M, C, ga.t.CVB, ga.t.PL, ga.RB,
-                           relu, (float *)dx, (float *)dres);
+    if (dtype == 0 && maskx)
+        MDX_BN_BWD(bn_nhwc_bwd_apply_kernel, float, true, grid_a, block, 0, st, (const float *)dy, (const float *)dy2, (const float *)y,
+                   (const float *)x, gamma, beta, save_mean, save_invstd, totals, M, C, ga.t.CVB, ga.t.PL, ga.RB, relu, (float *)dx, (float *)dres);
+    else if (dtype == 0)
+        MDX_BN_BWD(bn_nhwc_bwd_apply_kernel, float, false, grid_a, block, 0, st, (const float *)dy, (const float *)dy2, (const float *)y,
+                   (const float *)x, gamma, beta, save_mean, save_invstd, totals, M, C, ga.t.CVB, ga.t.PL, ga.RB, relu, (float *)dx, (float *)dres);
+    else if (maskx)
+        MDX_BN_BWD(bn_nhwc_bwd_apply_kernel, bf16, true, grid_a, block, 0, st, (const bf16 *)dy, (const bf16 *)dy2, (const bf16 *)y,
+                   (const bf16 *)x, gamma, beta, save_mean, save_invstd, totals, M, C, ga.t.CVB, ga.t.PL, ga.RB, relu, (bf16 *)dx, (bf16 *)dres);
     else
-        hipLaunchKernelGGL((bn_nhwc_bwd_apply_kernel<bf16>), grid_a, block, 0, st, (const bf16 *)dy, (const bf16 *)dy2,
-                           (const bf16 *)y, (const bf16 *)x, gamma, beta, save_mean, save_invstd, totals, M, C, ga.t.CVB, ga.t.PL, ga.RB,
-                           relu, (bf16 *)dx, (bf16 *)dres);
+        MDX_BN_BWD(bn_nhwc_bwd_apply_kernel, bf16, false, grid_a, block, 0, st, (const bf16 *)dy, (const bf16 *)dy2, (const bf16 *)y,
+                   (const bf16 *)x, gamma, beta, save_mean, save_invstd, totals, M, C, ga.t.CVB, ga.t.PL, ga.RB, relu, (bf16 *)dx, (bf16 *)dres);
+#undef MDX_BN_BWD
     return check_launch();
 }

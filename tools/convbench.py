@@ -75,7 +75,7 @@ def main():
     print("%-22s %-18s s p  n   fwd | dgrad | wgrad us   TFLOP/s fwd|dgrad|wgrad   floor us (flop|bytes)   share" % ("x", "w"))
     for r in rows:
         t3 = (r["fwd_us"], r["dgrad_us"], r["wgrad_us"])
-        tf = ["%5.1f" % (r["gflop"] / t * 1e-3) if t else "    -" for t in t3]
+        tf = ["%5.1f" % (r["gflop"] / t * 1e3) if t else "    -" for t in t3]          # GFLOP / us = 1e15 FLOP/s -> TFLOP/s
         peak = 2500.0 if a.bf16 else 157.0
         print("%-22s %-18s %d %d %2d  %6.1f | %6.1f | %6.1f   %s|%s|%s   %6.1f | %6.1f   %5.1f %%" % (
             "x".join(map(str, r["x"])), "x".join(map(str, r["w"])), r["stride"], r["pad"], r["count"], *t3, *tf,
