@@ -14,7 +14,7 @@
 #      it).  "hip_graph_form" in the line must say "split", "rank_ms_per_step" shows a straggler.
 #      if efficiency at N = 8 is far below that: compare with section E (eager, four buckets overlapping backward).
 # B. The whole step INCLUDING the exchange as ONE hipGraph per rank (MDX_DP_GRAPH=1).  Never run with N > 1 so far
-#    (model_tool/parallel.py: dp_graph_allowed); with one rank it is 1.5 % ahead of the split form (745.7 vs 734.9 images/s).
+#    (model_tool/parallel.py: dp_graph_allowed); with one rank it is 0.9 % ahead of the split form (805.8 vs 799.0 images/s).
 #      a hang or a divergence here (rank 0's loss differs from section A's by more than noise) means the capture of the
 #      communicator's stream does not replay in the same order on every rank: keep the split form and report.
 #      if B beats A at N = 8 by > 3 %: make MDX_DP_GRAPH=1 the default in model_tool/parallel.py: dp_graph_allowed.
@@ -23,9 +23,9 @@
 #      expected reading: "value" and "trainer_loop.value" highest at 2; if 4 (runtime default, MDX_HW_QUEUES=0) or 8 wins at
 #      N = 8, change the default in model_train.py / bench.py.
 # D. Can one host feed 8 ranks (no GPU needed): 8 DataLoader sets side by side; prints PASS / FAIL against 1.3 x what a bf16
-#    rank consumes (~1130 samples/s since round 5; pass --consume to change).
+#    rank consumes (~1780 samples/s since round 5; pass --consume to change).
 # E. The eager data-parallel step (four 32 MB buckets issued from inside backward, overlapping it): host-bound since round 5
-#    (~1900 launches per 16 ms step; 421-747 images/s on one GPU depending on the host), kept as the fallback.
+#    (~900 launches per 15 ms step; 421-810 images/s on one GPU depending on the host), kept as the fallback.
 set -u
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"; cd "$ROOT"
 OUT="$ROOT/scale_check_out"; mkdir -p "$OUT"
