@@ -603,6 +603,7 @@ def main():
     opt.grad_comm, opt.bucket_mb = args.grad_comm, args.bucket_mb
     opt.prologue = not args.no_prologue
     opt.fused_tail = not args.no_fused_tails
+    opt.shadow_weights = os.environ.get("MDX_SHADOW_WEIGHTS", "1") != "0"       # (A/B of mdx/shadow.py in bf16 runs)
     if args.no_fused_tails:
         from model_layer.depth_decoder import DepthDecoder
         from model_layer.pose_decoder import PoseDecoder

@@ -225,6 +225,16 @@ class trainer(object):
         return loader
 
     def batch_process(self, inputs):
+        # bf16 networks: every convolution weight cast ONCE, by one launch, before the two networks fork (and the weight gradients
+        # back by one launch at the end of backward) instead of by autocast around each convolution (mdx/shadow.py)
+        if (self.compute.amp == "bf16" and str(self.device).startswith("cuda") and torch.is_grad_enabled()
+                and getattr(self.opt, "shadow_weights", True)):
+            from mdx.shadow import bf16_weights
+            with bf16_weights(self.setting.raw_model.values()):
+                return self._batch_process(inputs)
+        return self._batch_process(inputs)
+
+    def _batch_process(self, inputs):
         outputs = {}
         if self._pose_beside_depth():
             # the separate pose network does not depend on the depth network: it runs on a side stream beside it (forward here,

@@ -241,14 +241,14 @@ def test_kitti_tree_training_and_eigen_style_evaluation(G, tmp_path):
 
 
 def _trainer_losses(graph, automask=False, noise="device", n=6, lr_change_at=4, amp="none", channels_last="auto", batches=None,
-                    frame_ids=(0, -1, 1), overlap_pose=True):
+                    frame_ids=(0, -1, 1), overlap_pose=True, shadow_weights=True):
     import importlib
     bench = importlib.import_module("bench")
     from model_train import trainer
     torch.manual_seed(0)
     opt = bench.make_opt(2, height=64, width=96, amp=amp, frame_ids=frame_ids)
     opt.use_automasking, opt.graph, opt.synthetic_length, opt.max_steps, opt.miopen_find = automask, graph, 16, 0, False
-    opt.noise, opt.channels_last, opt.overlap_pose = noise, channels_last, overlap_pose
+    opt.noise, opt.channels_last, opt.overlap_pose, opt.shadow_weights = noise, channels_last, overlap_pose, shadow_weights
     tr = trainer(opt)
     tr.setting.set_train()
     if batches is None:
@@ -306,6 +306,32 @@ def test_pose_network_beside_depth_network_follows_the_sequential_trajectory(G, 
     pa, pb = dict(tr1.setting.raw_model["pose_decoder"].named_parameters()), dict(tr0.setting.raw_model["pose_decoder"].named_parameters())
     for k in pa:       # six Adam steps of lr 1e-4: the weights agree far inside one step's change
         assert float((pa[k] - pb[k]).abs().max()) <= (6e-4 if amp == "none" else 3e-3), k
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_bf16_weight_shadows_follow_the_autocast_trajectory(G, graph, monkeypatch):
+    """mdx/shadow.py: the bf16 copies of the convolution weights made by ONE launch before the networks fork (and the weight
+    gradients cast back by one launch at the end of backward) against autocast's cast around every convolution -- the same roundings,
+    so the same losses up to the order of MIOpen's atomics; and the modules see their float32 parameters again afterwards."""
+    import mdx.shadow as shadow
+    made = []
+    plain = shadow._CastAll.forward
+
+    def spy(ctx, *masters):
+        made.append(len(masters))
+        return plain(ctx, *masters)
+    monkeypatch.setattr(shadow._CastAll, "forward", staticmethod(spy))
+    a, n0, tr0 = _trainer_losses(graph, amp="bf16", shadow_weights=True)
+    assert made and made[0] >= 40, made                 # every convolution weight of the four networks, the one-channel heads left out
+    del made[:]
+    b, n1, tr1 = _trainer_losses(graph, amp="bf16", shadow_weights=False)
+    assert not made and n0 == n1 == 6
+    np.testing.assert_allclose(a, b, rtol=5e-2, atol=1e-4)
+    np.testing.assert_allclose(a[:2], b[:2], rtol=2e-3, atol=1e-5)
+    for net in tr0.setting.raw_model.values():
+        for p in net.parameters():
+            assert isinstance(p, torch.nn.Parameter) and p.dtype == torch.float32
+            assert not p.requires_grad or (p.grad is not None and p.grad.dtype == torch.float32)
 
 
 def test_trainer_graph_replay_matches_eager(G):
