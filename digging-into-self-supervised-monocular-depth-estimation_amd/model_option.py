@@ -55,6 +55,12 @@ def options(argv=None):
                    help="synthetic dataset hands over KITTI-sized decoded frames (1242x375 uint8), as the KITTI loaders do with gpu_image_prep")
     p.add_argument("--resume", type=int, default=0,
                    help="restart after this many finished epochs from ./model_save/<save>/ (weights <key><N>.pt + state<N>.pt)")
+    p.add_argument("--native_adam", type=int, default=1,
+                   help="GPU: torch.optim.Adam(fused=True) with its step as ONE launch (mdx/optim.py, csrc/adam.hip); 0: torch's own step")
+    p.add_argument("--shadow_weights", type=int, default=1,
+                   help="--amp bf16: cast every convolution weight once per step by one launch (mdx/shadow.py); 0: autocast's cast per convolution")
+    p.add_argument("--fused_tail", type=int, default=1,
+                   help="GPU: the loss as one autograd node, the pose head's output -> projections in one launch (0: the reference's small torch ops)")
     p.add_argument("--overlap_pose", type=int, default=1,
                    help="1: the separate pose network runs on a side stream beside the depth network, forward and backward (many of "
                         "their kernels are too small to fill the GPU alone: +13 %% fp32, +32 %% bf16 on one MI355X); 0: one after the other")
