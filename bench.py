@@ -604,10 +604,14 @@ def main():
     opt.prologue = not args.no_prologue
     opt.fused_tail = not args.no_fused_tails
     opt.shadow_weights = os.environ.get("MDX_SHADOW_WEIGHTS", "1") != "0"       # (A/B of mdx/shadow.py in bf16 runs)
+    if os.environ.get("MDX_THIN_WGRAD", "1") == "0":                             # (A/B of csrc/thinconv_nhwc.hip)
+        from model_layer.depth_decoder import DepthDecoder as _DD
+        _DD.thin_wgrad = False
     if args.no_fused_tails:
         from model_layer.depth_decoder import DepthDecoder
         from model_layer.pose_decoder import PoseDecoder
         DepthDecoder.fused_heads = False
+        DepthDecoder.thin_wgrad = False
         PoseDecoder.fused_tail = False
     # MIOpen picks the tuned solvers from the shipped find-db in immediate mode already (fp32: same images/s as find
     # mode).  Find mode proper (--miopen-find) returns at once on a db hit but searches for minutes on a miss, so it

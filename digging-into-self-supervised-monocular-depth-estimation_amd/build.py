@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, os.environ.get("MDX_BUILD_NAME", "libmdx_hip.so"))    # MDX_BUILD_NAME + MDX_BUILD_DEFINES: A/B builds
-SOURCES = ["photo_fwd.hip", "photo_bwd.hip", "photo_train.hip", "photo_train_finish.hip", "photo_prologue.hip", "photo_abi.hip", "smooth.hip", "loss_total.hip", "adam.hip", "ops.hip", "glue.hip", "glue_nhwc.hip", "disp_head_nhwc.hip", "pose_head_nhwc.hip", "norm.hip", "norm_nhwc.hip", "pose.hip", "monitor.hip", "imgproc.hip"]
+SOURCES = ["photo_fwd.hip", "photo_bwd.hip", "photo_train.hip", "photo_train_finish.hip", "photo_prologue.hip", "photo_abi.hip", "smooth.hip", "loss_total.hip", "adam.hip", "ops.hip", "glue.hip", "glue_nhwc.hip", "disp_head_nhwc.hip", "thinconv_nhwc.hip", "pose_head_nhwc.hip", "norm.hip", "norm_nhwc.hip", "pose.hip", "monitor.hip", "imgproc.hip"]
 HEADERS = ["mdx_device.hpp", "mdx_common.hpp", "nhwc_common.hpp", "photo_common.hpp", "photo_train.hpp", "photo_train_math.hpp", "mdx_divtable.inc", os.path.join("..", "..", "include", "mdx.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # per-file additions.  photo_train.hip: the SLP vectorizer pairs neighbouring f32 ops into v_pk_* (no faster per element

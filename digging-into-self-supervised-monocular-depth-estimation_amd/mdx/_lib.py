@@ -58,6 +58,7 @@ SYMBOLS = {
     "mdx_pose_projection_fwd": C.c_int, "mdx_pose_projection_bwd": C.c_int,
     "mdx_bias_act_nhwc_workspace_bytes": C.c_size_t, "mdx_bias_act_nhwc_fwd": C.c_int, "mdx_bias_act_nhwc_bwd": C.c_int,
     "mdx_mean_bias_nhwc_fwd": C.c_int, "mdx_mean_bias_nhwc_bwd": C.c_int, "mdx_encoder_input_nhwc": C.c_int,
+    "mdx_thin_conv3x3_wgrad_workspace_bytes": C.c_size_t, "mdx_thin_conv3x3_wgrad": C.c_int,
     "mdx_disp_head_nhwc_workspace_bytes": C.c_size_t, "mdx_disp_head_nhwc_fwd": C.c_int, "mdx_disp_head_nhwc_bwd": C.c_int,
     "mdx_event_create": C.c_void_p, "mdx_event_destroy": None, "mdx_event_elapsed_us": C.c_int,
     "mdx_photometric_fwd_timed": C.c_int, "mdx_photometric_bwd_timed": C.c_int,

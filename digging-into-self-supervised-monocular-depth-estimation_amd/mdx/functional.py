@@ -905,6 +905,52 @@ def encoder_input(stack, mean=0.45, std=0.225, dtype=torch.float32):
     return out
 
 
+class _ThinConv3x3(torch.autograd.Function):
+    """conv2d(x, w) (3x3, no padding, no bias) whose WEIGHT gradient is csrc/thinconv_nhwc.hip's MFMA kernel; forward and data
+    gradient stay MIOpen's."""
+    ARGS = ([1, 1], [0, 0], [1, 1], False, [0, 0], 1)
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        return torch.ops.aten.convolution(x, weight, None, *_ThinConv3x3.ARGS)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.ops.aten.convolution_backward(gy, x, weight, None, *_ThinConv3x3.ARGS, [True, False, False])[0]
+        if ctx.needs_input_grad[1]:
+            B, Cin, Hp, Wp = x.shape
+            gy = _as(gy, True)
+            gw = torch.empty_like(weight)
+            nws = lib().mdx_thin_conv3x3_wgrad_workspace_bytes(B, Cin, 16, Hp - 2, Wp - 2)
+            ws = torch.empty(nws // 4 + 1, device=x.device, dtype=torch.float32)
+            check(lib().mdx_thin_conv3x3_wgrad(ptr(x, cl=True), ptr(gy, cl=True), ptr(gw, cl="any"), C.c_int64(gw.stride(0)),
+                                               C.c_int64(gw.stride(1)), C.c_int64(gw.stride(2)), C.c_int64(gw.stride(3)), B, Cin, 16,
+                                               Hp - 2, Wp - 2, ptr(ws), C.c_size_t(nws), stream()), "mdx_thin_conv3x3_wgrad")
+        return gx, gw
+
+
+def thin_conv_ok(x, weight):
+    """A 3x3 convolution thin_conv3x3 takes: float32 channels-last GPU map [B,Cin,h+2,w+2] with Cin 16 or 32, weight [16,Cin,3,3]
+    (dense, either memory format), w a multiple of 4, no autocast."""
+    return (x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and weight.dtype == torch.float32 and is_channels_last(x)
+            and tuple(weight.shape) == (16, x.shape[1], 3, 3) and x.shape[1] in (16, 32) and x.shape[3] > 2 and (x.shape[3] - 2) % 4 == 0
+            and x.shape[2] > 2 and (weight.is_contiguous() or weight.is_contiguous(memory_format=_CL)) and not torch.is_autocast_enabled())
+
+
+def thin_conv3x3(x, weight):
+    """conv2d(x, weight) for the decoder's thin convolutions (depth_decoder.py:96-106: 16 output channels on the two biggest maps)
+    with the weight gradient from one MFMA launch (csrc/thinconv_nhwc.hip: 101 us against MIOpen's 190 on the 16-channel map of
+    scale 0); forward and data gradient are MIOpen's.  x: the reflection-padded channels-last input."""
+    if not thin_conv_ok(x, weight):
+        raise _lib.MdxError("thin_conv3x3: needs a float32 channels-last map with 16 or 32 channels and a [16,Cin,3,3] weight, got %s %s"
+                            % (tuple(x.shape), tuple(weight.shape)))
+    return _ThinConv3x3.apply(x, weight)
+
+
 class _DispHead(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):

@@ -39,6 +39,7 @@ class ConvBlock(nn.Module):
 
 class DepthDecoder(nn.Module):
     fused_heads = True          # False: the heads as MIOpen convolution + bias + sigmoid (A/B, parity tests)
+    thin_wgrad = True           # False: MIOpen's weight gradient for the 16-channel stage convolutions too
 
     def __init__(self, num_ch_enc, scales=range(4), num_output_channels=1, use_skips=True):
         super().__init__()
@@ -93,7 +94,10 @@ class DepthDecoder(nn.Module):
         input_features = [to_layout(f, cl) for f in input_features]
 
         def conv(block, x):     # the stage convolution WITHOUT its bias: the glue call that consumes it adds it
-            return TF.conv2d(x, block.conv.conv.weight, None), block.conv.conv.bias
+            w = block.conv.conv.weight
+            if self.thin_wgrad and torch.is_grad_enabled() and F.thin_conv_ok(x, w):
+                return F.thin_conv3x3(x, w), block.conv.conv.bias      # 16 output channels: weight gradient by csrc/thinconv_nhwc.hip
+            return TF.conv2d(x, w, None), block.conv.conv.bias
         padded = F.decoder_glue(input_features[-1], None, elu=False, upsample=False)
         for i in (4, 3, 2, 1, 0):
             first, second = self._stage[i]

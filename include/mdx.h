@@ -400,6 +400,14 @@ int mdx_mean_bias_nhwc_bwd(const float *gout, void *dx, float *dbias, int B, int
 int mdx_encoder_input_nhwc(const float *const *src, int blocks, int groups, int n, int H, int W, float mean, float inv_std,
                            void *out, int dtype, void *stream);
 
+/* Weight gradient of the decoder's thin 3x3 convolutions   model_layer/depth_decoder.py:96-106 (16 output channels, 16 or 32 input
+ * channels, on the two biggest maps): x [B][h+2][w+2][Cin] the reflection-padded input, gy [B][h][w][16], float32 channels-last,
+ * w a multiple of 4 -> gweight, element (co, ci, ky, kx) at gweight[co * s_o + ci * s_c + ky * s_y + kx * s_x].  One MFMA launch
+ * (v_mfma_f32_16x16x4_f32; operands loaded as they lie in memory) + a finishing pass over the block partials (fixed order). */
+size_t mdx_thin_conv3x3_wgrad_workspace_bytes(int B, int Cin, int Cout, int h, int w);
+int mdx_thin_conv3x3_wgrad(const float *x, const float *gy, float *gweight, int64_t s_o, int64_t s_c, int64_t s_y, int64_t s_x, int B,
+                           int Cin, int Cout, int h, int w, void *workspace, size_t workspace_bytes, void *stream);
+
 /* The decoder's disparity heads   model_layer/depth_decoder.py:73-74,108-110: sigmoid(Conv3x3(C -> 1)(x)) on a channels-last map.
  * x [B][h+2][w+2][C] = the reflection-padded input (mdx_decoder_glue_nhwc_fwd's output), dtype 0 float32 / 1 bfloat16, C a
  * power-of-two multiple of the 16-byte vector (4 / 8 elements) up to 64 vectors; weight: float32, element (c, ky, kx) at

@@ -573,3 +573,29 @@ def test_encoder_input_equals_cat_normalise(F, blocks, groups, dtype):
     assert out.shape == ref.shape and _layout_is(out, True) and out.dtype == dtype
     assert torch.equal(out, ref)
     assert not F.FrameStack([[frames[0][0].requires_grad_(True)]]).ok()
+
+
+@pytest.mark.parametrize("wcl", [False, True])
+@pytest.mark.parametrize("cfg", [(2, 16, 8, 12), (1, 32, 5, 8), (3, 16, 7, 4), (2, 32, 33, 20), (12, 16, 48, 160)])
+def test_thin_conv3x3_weight_gradient_matches_float64(F, cfg, wcl):
+    """thin_conv3x3: the MFMA weight gradient of the decoder's 16-output-channel 3x3 convolutions (csrc/thinconv_nhwc.hip) against
+    the float64 convolution's; forward and data gradient are MIOpen's and are checked against it too."""
+    B, Cin, h, w = cfg
+    g = torch.Generator().manual_seed(4)
+    x = _leaf(torch.randn(B, Cin, h + 2, w + 2, generator=g), torch.float32, True)
+    wt = (0.1 * torch.randn(16, Cin, 3, 3, generator=g)).cuda()
+    if wcl:
+        wt = wt.contiguous(memory_format=torch.channels_last)
+    wt.requires_grad_(True)
+    gy = torch.randn(B, 16, h, w, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    assert F.thin_conv_ok(x, wt)
+    y = F.thin_conv3x3(x, wt)
+    gx, gw = torch.autograd.grad(y, (x, wt), gy)
+    assert gw.shape == wt.shape and gw.stride() == wt.stride()
+    xr, wr = x.detach().double().cpu().requires_grad_(True), wt.detach().double().cpu().contiguous().requires_grad_(True)
+    yr = torch.nn.functional.conv2d(xr, wr)
+    gxr, gwr = torch.autograd.grad(yr, (xr, wr), gy.double().cpu())
+    for a, r, tol in ((y, yr, 2e-6), (gx, gxr, 2e-6), (gw, gwr, 2e-6)):
+        assert float((a.double().cpu() - r).abs().max()) <= tol * float(r.abs().max())
+    assert not F.thin_conv_ok(x, torch.randn(8, Cin, 3, 3).cuda())                       # other output widths: MIOpen
+    assert not F.thin_conv_ok(torch.randn(1, 16, 6, 9).cuda().contiguous(memory_format=torch.channels_last), wt[:, :16])  # w % 4
