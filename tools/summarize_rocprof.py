@@ -15,7 +15,7 @@ FAMILIES = (("miopen conv:fwd", ("igemm_fwd", "conv_fwd", "ConvFwd")), ("miopen 
             ("mdx:bn_", ("bn_nhwc", "bn_act", "mdx::bn_")), ("mdx:decoder_glue", ("decoder_glue",)), ("mdx:maxpool", ("maxpool3s2",)),
             ("mdx:disp_head", ("disp_head",)), ("mdx:pose head / input", ("bias_act", "mean_bias", "colsum_scale", "encoder_input",
                                                                       "pose_projection", "param2matrix", "compose_projection")),
-            ("mdx:loss path", ("photometric", "smooth_multi", "train_finish", "loss_total")), ("mdx:adam", ("adam_step",)),
+            ("mdx:loss path", ("photometric", "smooth_multi", "train_finish", "loss_total")), ("mdx:adam", ("adam_step",)), ("mdx:thin conv wgrad (MFMA)", ("thin_wgrad",)),
             ("mdx:other", ("mdx::",)))
 
 
