@@ -310,10 +310,14 @@ __global__ __launch_bounds__(NB) void maxpool3s2_nhwc_bwd_kernel(const T *__rest
         for (int k = 0; k < 2; ++k) {
             const int yo = yo0 + i, xo = xo0 + k;
             ok[i][k] = i < ny && k < nx && yo < Ho && xo < Wo;
-            const size_t off = img + ((size_t)(ok[i][k] ? yo : yo0) * Wo + (ok[i][k] ? xo : xo0)) * C;
-            gv[i][k] = load_vec<T, N>(gout + off);
-            if (gout2) gw[i][k] = load_vec<T, N>(gout2 + off);
-            av[i][k] = load_vec<uint8_t, N>(arg + off);
+            gv[i][k] = Vec<T, N>{};
+            av[i][k] = Vec<uint8_t, N>{};
+            if (ok[i][k]) {            // an even coordinate lies in ONE window of its axis: 2.25 windows per pixel on average, not 4
+                const size_t off = img + ((size_t)yo * Wo + xo) * C;
+                gv[i][k] = load_vec<T, N>(gout + off);
+                if (gout2) gw[i][k] = load_vec<T, N>(gout2 + off);
+                av[i][k] = load_vec<uint8_t, N>(arg + off);
+            }
         }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
