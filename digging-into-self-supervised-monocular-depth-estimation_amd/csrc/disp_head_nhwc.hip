@@ -20,6 +20,8 @@ namespace mdx {
 namespace nhwc {
 
 constexpr int DH_NB = 256;
+constexpr int DH_N = 4;          // channels per thread, float32 AND bfloat16 (8 bfloat16 per thread doubled the accumulators: 192 registers,
+                                 // two waves per SIMD, the backward pass twice as slow as the float32 one)
 enum { MDX_F32 = 0, MDX_BF16 = 1 };   // the dtype codes of include/mdx.h
 
 template <typename T, int N>
@@ -37,7 +39,7 @@ __global__ __launch_bounds__(DH_NB) void disp_head_fwd_kernel(const T *__restric
                                                               long wsx, const float *__restrict__ bias, int Hp, int Wp, int C, int LP,
                                                               int R, float *__restrict__ out)
 {
-    constexpr int N = VecN<T>::N;
+    constexpr int N = DH_N;
     const int h = Hp - 2, w = Wp - 2;
     const int l = threadIdx.x % LP, cb = threadIdx.x / LP, CPB = DH_NB / LP;
     const int j = blockIdx.x * CPB + cb;
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(DH_NB) __attribute__((amdgpu_waves_per_eu(WAVES, 8)
                                                               long wsx, const float *__restrict__ g, const float *__restrict__ y, int Hp,
                                                               int Wp, int C, int LP, int R, T *__restrict__ gx, float *__restrict__ part)
 {
-    constexpr int N = VecN<T>::N;
+    constexpr int N = DH_N;
     extern __shared__ float lds[];               // [4 waves][9 * C] + [4]
     const int h = Hp - 2, w = Wp - 2;
     const int l = threadIdx.x % LP, cb = threadIdx.x / LP, CPB = DH_NB / LP;
@@ -220,7 +222,8 @@ __global__ __launch_bounds__(DF_C *DF_S) void disp_head_finish_kernel(const floa
 struct HeadGeom { int LP, CPB, R; dim3 grid; };
 static inline bool head_geom(int B, int rows, int cols, int C, int dtype, HeadGeom *g)
 {
-    const int N = dtype == MDX_F32 ? 4 : 8;
+    const int N = DH_N;
+    (void)dtype;
     if (C % N) return false;
     g->LP = C / N;
     if (g->LP < 1 || g->LP > 64 || (g->LP & (g->LP - 1))) return false;
@@ -291,7 +294,7 @@ MDX_EXPORT int mdx_disp_head_nhwc_bwd(const void *x, const float *weight, int64_
         hipLaunchKernelGGL((disp_head_bwd_kernel<float, 4>), g.grid, dim3(DH_NB), shmem, st, (const float *)x, weight, (long)w_stride_c,
                            (long)w_stride_ky, (long)w_stride_kx, gdisp, disp, h + 2, w + 2, C, g.LP, g.R, (float *)gx, part);
     else
-        hipLaunchKernelGGL((disp_head_bwd_kernel<bf16, 2>), g.grid, dim3(DH_NB), shmem, st, (const bf16 *)x, weight, (long)w_stride_c,
+        hipLaunchKernelGGL((disp_head_bwd_kernel<bf16, 4>), g.grid, dim3(DH_NB), shmem, st, (const bf16 *)x, weight, (long)w_stride_c,
                            (long)w_stride_ky, (long)w_stride_kx, gdisp, disp, h + 2, w + 2, C, g.LP, g.R, (bf16 *)gx, part);
     const int nblk = (int)(g.grid.x * g.grid.y * g.grid.z), cols = 9 * C + 1;
     hipLaunchKernelGGL(disp_head_finish_kernel, dim3((cols + DF_C - 1) / DF_C), dim3(DF_C * DF_S), 0, st, part, nblk, C,

@@ -990,10 +990,10 @@ class _DispHead(torch.autograd.Function):
 
 def disp_head_ok(x, weight):
     """Can disp_head take this padded map and this head's weight?  (channels-last GPU map, one output channel, 3x3, a channel count
-    that is a power-of-two number of 16-byte vectors up to 64.)"""
+    that is a power of two from 4 to 256.)"""
     if not (x.is_cuda and x.dim() == 4 and x.dtype in _DTYPE_CODE and is_channels_last(x)):
         return False
-    n = 16 // x.element_size()
+    n = 4                                  # channels per thread, either dtype (csrc/disp_head_nhwc.hip: DH_N)
     lp = x.shape[1] // n
     return (tuple(weight.shape) == (1, x.shape[1], 3, 3) and x.shape[1] % n == 0 and 1 <= lp <= 64 and lp & (lp - 1) == 0
             and x.shape[2] > 2 and x.shape[3] > 2)
@@ -1004,7 +1004,7 @@ def disp_head(x, weight, bias=None):
     channels-last input, weight [1,C,3,3], bias [1] -> disp [B,1,h,w] float32 (csrc/disp_head_nhwc.hip: one launch forward, one +
     a finishing pass backward; float32 accumulation whatever x's dtype)."""
     if not disp_head_ok(x, weight):
-        raise _lib.MdxError("disp_head: needs a channels-last GPU map [B,C,h+2,w+2] with C a power-of-two number of 16-byte vectors "
+        raise _lib.MdxError("disp_head: needs a channels-last GPU map [B,C,h+2,w+2] with C a power of two from 4 to 256 "
                             "and a [1,C,3,3] weight; got x %s %s, weight %s" % (tuple(x.shape), x.dtype, tuple(weight.shape)))
     return _DispHead.apply(x, weight, bias)
 

@@ -410,7 +410,7 @@ int mdx_thin_conv3x3_wgrad(const float *x, const float *gy, float *gweight, int6
 
 /* The decoder's disparity heads   model_layer/depth_decoder.py:73-74,108-110: sigmoid(Conv3x3(C -> 1)(x)) on a channels-last map.
  * x [B][h+2][w+2][C] = the reflection-padded input (mdx_decoder_glue_nhwc_fwd's output), dtype 0 float32 / 1 bfloat16, C a
- * power-of-two multiple of the 16-byte vector (4 / 8 elements) up to 64 vectors; weight: float32, element (c, ky, kx) at
+ * power of two from 4 to 256; weight: float32, element (c, ky, kx) at
  * weight[c * w_stride_c + ky * w_stride_ky + kx * w_stride_kx] (planar [1,C,3,3]: 9, 3, 1; channels-last: 1, 3C, C);
  * bias [1] (may be NULL) -> disp [B][h][w] float32.  One launch.
  * bwd: gdisp, disp [B][h][w] -> gx (x's dtype and shape), gweight (the weight's strides), gbias [1] (may be NULL): one launch
